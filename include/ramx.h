@@ -1,0 +1,234 @@
+/*
+ * ramx.h -- C-ABI of libramx.so: the MI355X-native RAMExtend extension loop.
+ *
+ * Plain C, plain pointers and sizes; no torch / HIP types cross this boundary.
+ * Two concentric seams:
+ *
+ *   seam 1  extend_alignment()-compatible entry      (replaces reference ram_extend.c:859-1258,
+ *           ramx_extend_alignment / ramx_extend_flat   declared ram_extend.h:9-13)
+ *   seam 2  thin device API  ramx_dev_*               (init / upload / run_direction / download /
+ *                                                       destroy; what seam 1 is built from)
+ *
+ * plus the surfaces either side of the path that the RAMExtend CLI needs:
+ *   ramx_get_matrix* / ramx_free_scoring_system       (replaces score_system.c:23-30,91-180,182-400)
+ *   ramx_load_sequence_subset_minimal                 (replaces sequence.c:505-923 + 942-976)
+ *   ramx_print_core_edges                             (replaces report.c:161-502)
+ *   ramx_allocate_score / ramx_free_score             (replaces bnw_extend.c:87-155; the device path
+ *                                                       keeps its own state, these are kept only so a
+ *                                                       caller written against the reference still links)
+ *
+ * There is NO CPU fallback behind any of these: every entry that computes runs the HIP kernels and
+ * fails loudly (message on stderr + non-zero status / exit(1) where the reference would exit) if
+ * no gfx950 device is usable.
+ */
+#ifndef RAMX_H
+#define RAMX_H
+
+#include <stdint.h>
+#include <stdio.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------------------------
+ * Data model -- layout-identical to the reference structs so a reference caller can pass its
+ * own objects (common.h:80-98, sequence.h:36-46, score_system.h:7-17).  When compiling inside
+ * the reference tree define RAMX_USE_REFERENCE_STRUCTS and include its headers first.
+ * ------------------------------------------------------------------------------------------ */
+#ifndef RAMX_USE_REFERENCE_STRUCTS
+enum CoreBoundFlag { L_BOUNDARY = 0, SEQ_BOUNDARY = 1, CORE_BOUNDARY = 2, EXT_BOUNDARY = 3 };
+
+struct coreAlignment
+{
+  struct coreAlignment *next;
+  int seqIdx;
+  uint64_t leftSeqPos;
+  uint64_t rightSeqPos;
+  char leftExtendable;
+  char rightExtendable;
+  uint64_t lowerSeqBound;
+  uint64_t upperSeqBound;
+  enum CoreBoundFlag lowerSeqBoundFlag;
+  enum CoreBoundFlag upperSeqBoundFlag;
+  int leftExtensionLen;
+  int rightExtensionLen;
+  int score;
+  char orient;
+};
+
+struct sequenceLibrary
+{
+  char *sequence;
+  char **identifiers;
+  uint64_t *boundaries;
+  uint64_t *offsets;
+  uint64_t length;
+  int count;
+  int markov_chain_order;
+  uint32_t **markov_chain_prob_tables;
+};
+
+struct scoringSystem
+{
+  char *name;
+  int **matrix;
+  int msize;
+  char *alphabet;
+  double m_lambda;
+  double m_bg_freqs[4];
+  int gapopen;
+  int gapextn;
+};
+#endif
+
+/* base codes, reference sequence.h:7-15 */
+#define RAMX_SYM_N 99
+
+/* ------------------------------------------------------------------------------------------
+ * Seam 1: the extension loop
+ * ------------------------------------------------------------------------------------------ */
+
+/* The three globals the reference reads inside the hot path (ram_extend.c:40 `l`, :52 `VERBOSE`,
+ * :61 `WHEN_TO_STOP`).  Call before ramx_extend_alignment; defaults are 0 / 100 / 1. */
+void ramx_set_runtime(int verbose, int when_to_stop, int l);
+
+/* Drop-in for reference extend_alignment (ram_extend.h:9-13, ram_extend.c:859-1258): same
+ * arguments, same return value (max_extension_score_row_idx + 1), same side effects on
+ * master[], coreAlign[*].{left,right}ExtensionLen and .score, same stdout lines at VERBOSE<10.
+ * `score` (the reference's int**** DP state) is ignored: state lives in HBM.  pathStringFile
+ * (-outmat) must be NULL: the per-cell path dump is not produced by the device path and the
+ * call exits(1) with a message if it is requested. */
+int ramx_extend_alignment(int direction, struct coreAlignment *coreAlign, int ****score,
+                          struct sequenceLibrary *seqLib, char *master, int BANDWIDTH,
+                          int CAPPENALTY, int MINIMPROVEMENT, int L, int N,
+                          struct scoringSystem *scoreParams, FILE *pathStringFile);
+
+/* Same loop on flat arrays (what ramx_extend_alignment flattens to, and what the Python mirror
+ * binds).  matrix is int32[100*100], row-major [consensus][sequence base].  Returns the
+ * reference's return value, or a negative ramx error code. */
+typedef struct ramx_flat_cores
+{
+  int32_t n;
+  const int64_t *left_pos, *right_pos, *lower, *upper;
+  const int8_t *orient, *left_ext, *right_ext;
+  int32_t *left_len, *right_len, *score;       /* in/out */
+} ramx_flat_cores;
+
+typedef struct ramx_params
+{
+  int32_t bandwidth, cappenalty, minimprovement, L, when_to_stop, l, gapopen, gapextn;
+  const int32_t *matrix;
+} ramx_params;
+
+typedef struct ramx_run_info
+{
+  int32_t ret;              /* max_extension_score_row_idx + 1 */
+  int32_t rows_executed;    /* row_idx iterations executed (the metric's "columns") */
+  int32_t limit_warning;    /* 1 iff the reference would print "WARNING: Extended ... to the limit" */
+  int32_t overflow32;       /* 1 iff a column sum left the int32 range (reference would have wrapped) */
+  int32_t n_extendable;     /* flanks on the device in this direction */
+  int32_t launches;         /* column-kernel launches issued (>= rows_executed: the host runs ahead) */
+  double  loop_ms;          /* HIP-event time of the column loop on the library's stream */
+  double  kernel_ms_avg;    /* mean duration of sampled single column-kernel launches (HIP events) */
+  int32_t kernel_samples;
+  double  prep_ms;          /* host flatten + H2D + pack kernel (wall clock) */
+} ramx_run_info;
+
+int ramx_extend_flat(int direction, ramx_flat_cores *cores, const int8_t *sequence, uint64_t seq_len,
+                     int8_t *master, const ramx_params *p, ramx_run_info *info);
+
+/* ------------------------------------------------------------------------------------------
+ * Seam 2: thin device API (one ramx_dev per GPU / per process rank)
+ * ------------------------------------------------------------------------------------------ */
+typedef struct ramx_dev ramx_dev;
+
+#define RAMX_OK            0
+#define RAMX_ERR_NO_DEVICE (-101)
+#define RAMX_ERR_HIP       (-102)
+#define RAMX_ERR_ARG       (-103)
+#define RAMX_ERR_STATE     (-104)
+#define RAMX_ERR_COMM      (-105)
+#define RAMX_ERR_UNSUPPORTED (-106)
+
+const char *ramx_last_error(void);
+int ramx_device_count(void);                                   /* gfx950 devices visible; <0 on error */
+int ramx_dev_create(int device_ordinal, ramx_dev **out);       /* init */
+void ramx_dev_destroy(ramx_dev *d);                            /* destroy */
+
+/* upload: the 1-byte-per-base library (seqLib->sequence) goes to HBM once and is shared by both
+ * directions. */
+int ramx_dev_load_library(ramx_dev *d, const int8_t *sequence, uint64_t length);
+
+/* One flank (an extendable core seen from one direction), already resolved by the host:
+ * the base aligned to band cell (row r, offset o) is library[start + step*(o + r)], complemented
+ * if compl != 0, and is inside the flank iff t_lo <= o + r <= t_hi  (SURVEY.md App. D rule 1). */
+typedef struct ramx_flank
+{
+  int64_t start;
+  int32_t t_lo, t_hi;
+  int8_t  step;       /* +1 / -1 */
+  int8_t  compl_;     /* reverse-strand core: complement the base */
+  int8_t  pad_[6];
+} ramx_flank;
+
+/* upload (per direction): flank descriptors -> HBM, pack kernel builds the transposed 4-bit
+ * windows, DP state / vote / control buffers are (re)initialised. */
+int ramx_dev_begin_direction(ramx_dev *d, const ramx_flank *flanks, int32_t n_flanks, const ramx_params *p);
+
+/* run_direction: the whole column loop, asynchronous on the device's stream with the stop rule
+ * evaluated on the device; returns when the loop has stopped. */
+int ramx_dev_run_direction(ramx_dev *d, ramx_run_info *info);
+
+/* download: consensus bases of the executed columns (cons[0..rows_executed)), and the
+ * trimmed per-flank high score / position (trimmed_sequence_high_score[_pos], ram_extend.c:902-903). */
+int ramx_dev_download(ramx_dev *d, int8_t *cons, int32_t cons_cap, int32_t *trim_high, int32_t *trim_pos);
+
+/* debug / test hook: current DP row state of one flank as [2W+1][2] int32 (sub,gap) + high,pos */
+int ramx_dev_peek_state(ramx_dev *d, int32_t flank, int32_t *cells, int32_t *high, int32_t *pos);
+
+/* multi-GPU: flanks are sharded over ranks; each column's 4 candidate sums are all-reduced
+ * (4 x int64, RCCL over xGMI).  unique_id is the 128-byte ncclUniqueId made by rank 0
+ * (ramx_comm_unique_id) and handed to the other ranks by the launcher (e.g. torch.distributed). */
+int ramx_comm_unique_id(uint8_t id[128]);
+int ramx_dev_comm_init(ramx_dev *d, const uint8_t id[128], int rank, int nranks);
+/* test hook: replaces RCCL by a caller-supplied all-reduce so the sharded control flow can be
+ * exercised without a GPU collective (cb must sum 4 int64 in place across ranks, blocking). */
+typedef void (*ramx_allreduce_cb)(long long *vals4, void *user);
+
+/* ------------------------------------------------------------------------------------------
+ * Scoring systems (reference score_system.h:23-37)
+ * ------------------------------------------------------------------------------------------ */
+struct scoringSystem *ramx_get_matrix(const char *matrixName);                       /* getMatrix */
+struct scoringSystem *ramx_get_matrix_using_gap_penalties(const char *matrixName,
+                                                          int gapopen, int gapextn); /* getMatrixUsingGapPenalties */
+struct scoringSystem *ramx_get_repeatscout_matrix(int match, int mismatch, int gap); /* getRepeatScoutMatrix */
+void ramx_free_scoring_system(struct scoringSystem *s);                              /* freeScoringSystem */
+double ramx_calculate_lambda(struct scoringSystem *s);                               /* calculateLambda */
+
+/* ------------------------------------------------------------------------------------------
+ * Input surface (reference sequence.h:58-61): BED-6 ranges + 2bit -> library + cores
+ * ------------------------------------------------------------------------------------------ */
+struct sequenceLibrary *ramx_load_sequence_subset_minimal(const char *twoBitName, const char *rangeBEDName,
+                                                          struct coreAlignment **core_align,
+                                                          int *num_cores, int max_flanking_bp);
+void ramx_free_library(struct sequenceLibrary *lib, struct coreAlignment *cores);
+
+/* overlap avoidance between the two directions (reference ram_extend.c:445-499), prints the same lines */
+void ramx_overlap_avoidance(struct coreAlignment *coreAlign, struct sequenceLibrary *seqLib);
+
+/* report.c:161-502 */
+void ramx_print_core_edges(struct coreAlignment *coreAlign, struct sequenceLibrary *seqLib,
+                           char omitBlanks, char debug);
+
+/* bnw_extend.c:87-155 -- link compatibility only (see top of file) */
+int ****ramx_allocate_score(int num_align, int bandwidth);
+void ramx_free_score(int num_align, int bandwidth, int ****score);
+
+/* the CLI, callable as a function (RAMExtend's main(); reference ram_extend.c:217-790) */
+int ramx_cli_main(int argc, char **argv);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,752 @@
+// ramx_device.hip -- seam 2 of include/ramx.h: the thin device API and the gfx950 kernels.
+//
+// Replaces, on the device, the reference's per-column work:
+//   compute_nw_row            bnw_extend.c:750-1048   (banded affine row, 2 states per cell)
+//   candidate vote + cap      ram_extend.c:973-1086
+//   recompute-with-winner     ram_extend.c:1097-1168  (folded away: see "column step" below)
+//   fit-preferred stop rule   ram_extend.c:1169-1223
+//   boundary row              ram_extend.c:909-960
+//
+// Layout in HBM (Np = flanks padded to a multiple of 64, W = half band, B = 2W+1, Q = W+1):
+//   bases  uint32 [KW][Np]        4-bit base classes, 8 per word, pre-oriented per flank so that
+//                                 nibble (t' & 7) of word (t' >> 3) is the base aligned to band
+//                                 cell (row r, offset o) with t' = o + r + W.  Transposed: the 64
+//                                 lanes of a wave read 256 contiguous bytes.
+//   state  int4   [Np/64][Q][64]  one DP row per flank: slot q holds cells 2q and 2q+1 as
+//                                 (sub,gap,sub,gap); the last slot holds cell B-1 and (high,pos)
+//                                 (overall_sequence_high_score[_pos], ram_extend.c:900-901).
+//                                 Exactly 16*B+16 bytes per flank, read once and written once per
+//                                 column: the algorithmic traffic of SURVEY.md section 8(d).
+//   trim   int2   [Np]            trimmed_sequence_high_score[_pos] (ram_extend.c:902-903)
+//   sums   int64  [3][32][4]      sharded per-candidate column sums (vote), rotated by column
+//   ctl    RamxCtl[2]             stop-rule state, flip-flopped by column
+//
+// Column step K(r), one launch per consensus column, ONE LANE PER FLANK:
+//   every wave:  fold the 32x4 vote shards of row r -> besta(r), new-max / stop decision
+//   every lane:  stream its previous row S(r-1) (coalesced 16 B loads, 8 deep in flight),
+//                compute row r against besta(r) -> S(r) (stored), track best cell -> high/pos,
+//                and, skewed by one cell, the four candidate rows r+1 from S(r) (never stored) ->
+//                capped contributions -> wave shuffle reduce -> LDS block reduce -> 4 int64 atomics
+//                into one of 32 shards.
+// The serial dependency through the insertion term (cells -W..+W in order) stays a plain serial
+// loop inside the lane, so the values are the reference's bit for bit; parallelism comes from the
+// flanks (N >= 64 k fills the chip).  No MFMA: integer max-plus recurrences, HBM-bound.
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include "ramx_internal.h"
+
+#define NEG RAMX_NEG_IMPOSSIBLE
+#define SENT RAMX_OOB_SENTINEL
+#define NSHARD 32
+#define PF 8            // state slots kept in flight per lane
+#define MAX_SAMPLES 64
+
+struct RamxCtl
+{
+  long long max_ext;   // max_extension_score
+  int max_row;         // max_extension_score_row_idx
+  int stopped;
+  int rows_done;       // row_idx iterations executed so far
+  int overflow;        // a column sum left the int32 range
+  int besta;
+  int pad;
+};
+
+struct KArgs
+{
+  const int4 *S_in;
+  int4 *S_out;
+  const unsigned *bases;
+  const int2 *bounds;
+  int2 *trim;
+  const long long *sums_in;
+  long long *sums_out;
+  long long *sums_zero;
+  const RamxCtl *ctl_in;
+  RamxCtl *ctl_out;
+  signed char *cons_out;
+  int Np, Nx, W, r, go, ge, cap, minimp, when_to_stop, nshards_in;
+  int tab[RAMX_NCLASS][4];   // tab[class][candidate] = matrix[candidate][class]
+};
+
+// ------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------
+static thread_local char g_err[512];
+
+extern "C" void ramx_set_error(const char *fmt, ...)
+{
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char *ramx_last_error(void) { return g_err; }
+
+#define HIPCHK(call)                                                                              \
+  do {                                                                                            \
+    hipError_t e_ = (call);                                                                       \
+    if (e_ != hipSuccess) {                                                                       \
+      ramx_set_error("HIP error %s at %s:%d (%s)", hipGetErrorString(e_), __FILE__, __LINE__, #call); \
+      return RAMX_ERR_HIP;                                                                        \
+    }                                                                                             \
+  } while (0)
+
+static double now_ms(void)
+{
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+
+// ------------------------------------------------------------------------------------------
+// pack kernel: 1-byte library -> transposed, pre-oriented 4-bit windows
+// ------------------------------------------------------------------------------------------
+__global__ void ramx_pack_kernel(const signed char *__restrict__ lib, unsigned long long lib_len,
+                                 const ramx_flank *__restrict__ fl, int Nx, int Np, int W,
+                                 unsigned *__restrict__ bases, int2 *__restrict__ bounds)
+{
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  const int k = blockIdx.y;
+  if (n >= Np) return;
+  unsigned word = 0x88888888u;   // class 8 = N everywhere
+  if (n < Nx)
+  {
+    const ramx_flank f = fl[n];
+    word = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+    {
+      const int t = 8 * k + i - W;
+      unsigned c = 8;
+      if (t >= f.t_lo && t <= f.t_hi)
+      {
+        const long long p = f.start + (long long)f.step * t;
+        if (p >= 0 && (unsigned long long)p < lib_len)
+        {
+          const int b = lib[p];
+          if (b >= 0 && b <= 7)   // A C G T a c g t; complement keeps the case (sequence.c:1141-1160)
+            c = f.compl_ ? (unsigned)((b & 4) | (3 - (b & 3))) : (unsigned)b;
+        }
+      }
+      word |= c << (4 * i);
+    }
+    if (k == 0) bounds[n] = make_int2(f.t_lo + W, f.t_hi + W);
+  }
+  else if (k == 0)
+    bounds[n] = make_int2(1, 0);   // empty interval: every cell out of bounds
+  bases[(size_t)k * Np + n] = word;
+}
+
+// ------------------------------------------------------------------------------------------
+// column kernel
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ long long wave_sum_ll(long long v)
+{
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+
+// One band step j of the skewed pair {row r cell j, candidate rows r+1 cell j-1}.
+//   INIT : row "r" is the boundary row (ram_extend.c:909-946), generated instead of computed
+//   VIRT : j == B, only the candidates' last cell is evaluated
+template <bool INIT, bool VIRT>
+__device__ __forceinline__ void band_step(const KArgs &a, const int4 *s_tab, int j, int besta,
+                                          int Psub, int Pgap, int EPn, unsigned bcode, bool inb, int vF,
+                                          int vC, int &eC, int &mPrev, int &bestF, int &jbest,
+                                          int (&eA)[4], int (&bestA)[4], int &outSub, int &outGap)
+{
+  const int go = a.go, ge = a.ge;
+  const int4 s = s_tab[bcode];
+  int eCnew;
+  int m = 0;
+  if (VIRT)
+  {
+    eCnew = NEG - ge;   // so that the candidates' deletion term is exactly NEG (no cell B)
+  }
+  else
+  {
+    int sub, gap;
+    if (INIT)
+    {
+      const int o = j - a.W;
+      sub = (o == 0) ? 0 : (go + (o < 0 ? -o : o) * ge);
+      gap = sub;
+      m = sub;
+    }
+    else
+    {
+      const int sF = (besta & 2) ? ((besta & 1) ? s.w : s.z) : ((besta & 1) ? s.y : s.x);
+      const int pm = Psub > Pgap ? Psub : Pgap;
+      sub = pm + sF;                              // bnw_extend.c:950-956
+      const int del = EPn + ge;                   // :892-905
+      const int ins = eC + ge;                    // :972-985
+      gap = ins > del ? ins : del;                // :1007-1010
+      sub = inb ? sub : vF;                       // :990-1002
+      gap = inb ? gap : vF;
+      m = gap > sub ? gap : sub;                  // :1015-1018
+      if (m > bestF) { bestF = m; jbest = j; }    // :1020-1024 (strict >: lowest offset wins ties)
+    }
+    outSub = sub;
+    outGap = gap;
+    const int so = sub + go;
+    eCnew = so > gap ? so : gap;
+  }
+  if (j > 0)
+  {
+    const int delC = eCnew + ge;
+    const int sv[4] = { s.x, s.y, s.z, s.w };
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+    {
+      int subA = mPrev + sv[c];
+      const int insA = eA[c] + ge;
+      int gapA = insA > delC ? insA : delC;
+      subA = inb ? subA : vC;
+      gapA = inb ? gapA : vC;
+      const int cA = gapA > subA ? gapA : subA;
+      bestA[c] = cA > bestA[c] ? cA : bestA[c];
+      const int so = subA + go;
+      eA[c] = so > gapA ? so : gapA;
+    }
+  }
+  mPrev = m;
+  eC = eCnew;
+}
+
+template <bool INIT, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void ramx_column_kernel(const KArgs a)
+{
+  constexpr int WPB = BLOCK / 64;
+  __shared__ int4 s_tab[RAMX_NCLASS];
+  __shared__ long long s_red[WPB][4];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+
+  if (threadIdx.x < RAMX_NCLASS)
+    s_tab[threadIdx.x] = make_int4(a.tab[threadIdx.x][0], a.tab[threadIdx.x][1], a.tab[threadIdx.x][2],
+                                   a.tab[threadIdx.x][3]);
+
+  // ---- vote for row r, stop rule (every wave, redundantly; block 0 publishes) -------------
+  int besta = 0;
+  bool new_max = false;
+  if (!INIT)
+  {
+    const RamxCtl c = *a.ctl_in;
+    if (c.stopped) return;   // uniform: the host runs ahead of the device-side stop decision
+    long long v[4] = { 0, 0, 0, 0 };
+    if (lane < a.nshards_in)
+    {
+      const long long *p = a.sums_in + lane * 4;
+      v[0] = p[0]; v[1] = p[1]; v[2] = p[2]; v[3] = p[3];
+    }
+    long long curr = 0;      // ram_extend.c:973-974
+    int ovf = c.overflow;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+    {
+      v[k] = wave_sum_ll(v[k]);
+      if (v[k] > 2147483647LL || v[k] < -2147483648LL) ovf = 1;
+      if (v[k] > curr) { curr = v[k]; besta = k; }   // :1081-1085 strict >, ties -> lowest base
+    }
+    int dist = c.max_row - a.r;
+    dist = dist < 0 ? -dist : dist;
+    new_max = curr >= c.max_ext + (long long)dist * a.minimp;   // :1194-1196
+    const int max_row = new_max ? a.r : c.max_row;
+    const long long max_ext = new_max ? curr : c.max_ext;
+    int d2 = a.r - max_row;
+    d2 = d2 < 0 ? -d2 : d2;
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+    {
+      RamxCtl o;
+      o.max_ext = max_ext; o.max_row = max_row; o.stopped = (d2 >= a.when_to_stop) ? 1 : 0;   // :1216
+      o.rows_done = a.r + 1; o.overflow = ovf; o.besta = besta; o.pad = 0;
+      *a.ctl_out = o;
+      a.cons_out[a.r] = (signed char)besta;   // :1092-1095 (host scatters into master[])
+    }
+  }
+  else if (blockIdx.x == 0 && threadIdx.x == 0)
+  {
+    RamxCtl o;
+    o.max_ext = 0; o.max_row = -1; o.stopped = 0; o.rows_done = 0; o.overflow = 0; o.besta = 0; o.pad = 0;
+    *a.ctl_out = o;
+  }
+  if (blockIdx.x == 0)
+    for (int i = threadIdx.x; i < NSHARD * 4; i += BLOCK) a.sums_zero[i] = 0;
+  __syncthreads();
+
+  // ---- the band: one lane = one flank -----------------------------------------------------
+  const int W = a.W, B = 2 * W + 1, Q = W + 1;
+  const int tile = blockIdx.x * WPB + wave;
+  long long contrib[4] = { 0, 0, 0, 0 };
+  if (tile < (a.Np >> 6))
+  {
+    const int n = tile * 64 + lane;
+    const int2 bd = a.bounds[n];
+    const int jlo = bd.x - a.r, jhi = bd.y - a.r;     // cell j is in bounds iff jlo <= j <= jhi
+    const int4 *Sin = a.S_in + (size_t)tile * Q * 64 + lane;
+    int4 *Sout = a.S_out + (size_t)tile * Q * 64 + lane;
+
+    // OOB fill values (bnw_extend.c:990-1002): uniform per (row, cell)
+    const int edgeF = (a.r < W) ? a.go + (a.r + 1) * a.ge : SENT;       // row r,   cells j < W
+    const int edgeC = (a.r + 1 < W) ? a.go + (a.r + 2) * a.ge : SENT;   // row r+1, cells j < W
+
+    // base words: t' = j + r runs over [max(r,0), r + B]; keep two words of lookahead
+    const int tp0 = a.r < 0 ? 0 : a.r;
+    int kw = tp0 >> 3;
+    const unsigned *bp = a.bases + n;
+    unsigned w0 = bp[(size_t)kw * a.Np];
+    unsigned w1 = bp[(size_t)(kw + 1) * a.Np];
+    unsigned w2 = bp[(size_t)(kw + 2) * a.Np];
+
+    int4 buf[PF];
+    if (!INIT)
+    {
+#pragma unroll
+      for (int i = 0; i < PF; i++) buf[i] = Sin[(size_t)(i < Q ? i : Q - 1) * 64];
+    }
+
+    int eC = NEG - a.ge, mPrev = 0, bestF = NEG, jbest = 0;
+    int eA[4] = { NEG - a.ge, NEG - a.ge, NEG - a.ge, NEG - a.ge };
+    int bestA[4] = { NEG, NEG, NEG, NEG };
+    int high = 0, pos = 0;
+    int lastSub = 0, lastGap = 0;
+
+    for (int q0 = 0; q0 < Q; q0 += PF)
+    {
+#pragma unroll
+      for (int i = 0; i < PF; i++)
+      {
+        const int q = q0 + i;
+        if (q < Q)
+        {
+          int4 cur = make_int4(0, 0, 0, 0), nxt = make_int4(0, 0, 0, 0);
+          if (!INIT)
+          {
+            cur = buf[i];
+            nxt = buf[(i + 1) % PF];
+            const int qn = q + PF;
+            buf[i] = Sin[(size_t)(qn < Q ? qn : Q - 1) * 64];
+          }
+          // ---- even cell j = 2q (always a real cell) ----
+          {
+            const int j = 2 * q;
+            int tp = j + a.r; tp = tp < 0 ? 0 : tp;
+            if ((tp >> 3) != kw) { kw++; w0 = w1; w1 = w2; w2 = bp[(size_t)(kw + 2) * a.Np]; }
+            const unsigned bc = (w0 >> (4 * (tp & 7))) & 15u;
+            const bool inb = (j >= jlo) && (j <= jhi);
+            const int vF = (j < W) ? edgeF : SENT;
+            const int vC = (j - 1 < W) ? edgeC : SENT;
+            int EPn;
+            if (q < W) { const int so = cur.z + a.go; EPn = so > cur.w ? so : cur.w; }
+            else EPn = NEG - a.ge;    // cell B-1 has no deletion predecessor (bnw_extend.c:892)
+            int oS, oG;
+            band_step<INIT, false>(a, s_tab, j, besta, cur.x, cur.y, EPn, bc, inb, vF, vC, eC, mPrev, bestF,
+                                   jbest, eA, bestA, oS, oG);
+            lastSub = oS; lastGap = oG;
+          }
+          if (q < W)
+          {
+            // ---- odd cell j = 2q+1 ----
+            const int j = 2 * q + 1;
+            int tp = j + a.r; tp = tp < 0 ? 0 : tp;
+            if ((tp >> 3) != kw) { kw++; w0 = w1; w1 = w2; w2 = bp[(size_t)(kw + 2) * a.Np]; }
+            const unsigned bc = (w0 >> (4 * (tp & 7))) & 15u;
+            const bool inb = (j >= jlo) && (j <= jhi);
+            const int vF = (j < W) ? edgeF : SENT;
+            const int vC = (j - 1 < W) ? edgeC : SENT;
+            const int so = nxt.x + a.go;
+            const int EPn = so > nxt.y ? so : nxt.y;
+            int oS, oG;
+            band_step<INIT, false>(a, s_tab, j, besta, cur.z, cur.w, EPn, bc, inb, vF, vC, eC, mPrev, bestF,
+                                   jbest, eA, bestA, oS, oG);
+            Sout[(size_t)q * 64] = make_int4(lastSub, lastGap, oS, oG);
+          }
+          else
+          {
+            // ---- q == W: slot holds cell B-1 and (high,pos); virtual step j = B for the candidates ----
+            const int j = B;
+            int tp = j + a.r; tp = tp < 0 ? 0 : tp;
+            if ((tp >> 3) != kw) { kw++; w0 = w1; w1 = w2; w2 = bp[(size_t)(kw + 2) * a.Np]; }
+            const unsigned bc = (w0 >> (4 * (tp & 7))) & 15u;
+            const bool inb = (j >= jlo) && (j <= jhi);
+            const int vC = (j - 1 < W) ? edgeC : SENT;
+            int oS, oG;
+            band_step<INIT, true>(a, s_tab, j, besta, 0, 0, 0, bc, inb, SENT, vC, eC, mPrev, bestF, jbest, eA,
+                                  bestA, oS, oG);
+            if (!INIT)
+            {
+              high = cur.z; pos = cur.w;
+              if (bestF > high) { high = bestF; pos = a.r + jbest - W; }   // ram_extend.c:1140-1150
+            }
+            Sout[(size_t)q * 64] = make_int4(lastSub, lastGap, high, pos);
+          }
+        }
+      }
+    }
+    if (INIT || new_max) a.trim[n] = make_int2(high, pos);   // ram_extend.c:1203-1207 (913-914 at init)
+    if (n < a.Nx)
+    {
+      const int capv = high + a.cap;
+#pragma unroll
+      for (int c = 0; c < 4; c++)
+      {
+        int b = bestA[c] < 0 ? 0 : bestA[c];                   // ram_extend.c:1042
+        contrib[c] = (b >= capv) ? b : capv;                   // :1052-1062
+      }
+    }
+  }
+
+  // ---- 64 lanes -> wave -> block -> one int64 atomic per candidate into this block's shard ----
+#pragma unroll
+  for (int c = 0; c < 4; c++) contrib[c] = wave_sum_ll(contrib[c]);
+  if (lane == 0)
+  {
+#pragma unroll
+    for (int c = 0; c < 4; c++) s_red[wave][c] = contrib[c];
+  }
+  __syncthreads();
+  if (threadIdx.x < 4)
+  {
+    long long t = 0;
+#pragma unroll
+    for (int wv = 0; wv < WPB; wv++) t += s_red[wv][threadIdx.x];
+    atomicAdd((unsigned long long *)(a.sums_out + (blockIdx.x % NSHARD) * 4 + threadIdx.x), (unsigned long long)t);
+  }
+}
+
+// multi-GPU: fold the local shards to 4 values so RCCL moves exactly 4 x int64 per column
+__global__ void ramx_fold_kernel(const long long *sums, long long *g)
+{
+  const int lane = threadIdx.x;
+  long long v[4] = { 0, 0, 0, 0 };
+  if (lane < NSHARD) { v[0] = sums[lane * 4]; v[1] = sums[lane * 4 + 1]; v[2] = sums[lane * 4 + 2]; v[3] = sums[lane * 4 + 3]; }
+#pragma unroll
+  for (int k = 0; k < 4; k++) v[k] = wave_sum_ll(v[k]);
+  if (lane == 0) { g[0] = v[0]; g[1] = v[1]; g[2] = v[2]; g[3] = v[3]; }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side of seam 2
+// ------------------------------------------------------------------------------------------
+struct ramx_dev
+{
+  int ordinal;
+  hipStream_t stream;
+  signed char *d_lib; unsigned long long lib_len; unsigned long long lib_cap;
+  // per direction
+  ramx_flank *d_flanks; unsigned *d_bases; int2 *d_bounds; int4 *d_state[2]; int2 *d_trim;
+  long long *d_sums; long long *d_g; RamxCtl *d_ctl; signed char *d_cons;
+  size_t cap_flanks, cap_bases, cap_state, cap_cons;
+  RamxCtl *h_ctl;   // pinned, [2 checkpoints][2 slots]
+  hipEvent_t ev_chk[2], ev_begin, ev_end, ev_s0[MAX_SAMPLES], ev_s1[MAX_SAMPLES];
+  int Nx, Np, KW;
+  ramx_params p; int tab[RAMX_NCLASS][4];
+  int ready;
+  RamxCtl final_ctl;
+  // multi-GPU
+  ncclComm_t comm; int rank, nranks;
+  int block;
+};
+
+extern "C" int ramx_device_count(void)
+{
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) { ramx_set_error("hipGetDeviceCount: %s", hipGetErrorString(e)); return RAMX_ERR_NO_DEVICE; }
+  return n;
+}
+
+extern "C" int ramx_dev_create(int ordinal, ramx_dev **out)
+{
+  int n = ramx_device_count();
+  if (n <= 0) { ramx_set_error("no HIP device visible (libramx has no CPU path)"); return RAMX_ERR_NO_DEVICE; }
+  if (ordinal < 0 || ordinal >= n) { ramx_set_error("device ordinal %d out of range (%d devices)", ordinal, n); return RAMX_ERR_ARG; }
+  HIPCHK(hipSetDevice(ordinal));
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, ordinal));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+  {
+    ramx_set_error("device %d is %s; libramx carries gfx950 code objects only", ordinal, prop.gcnArchName);
+    return RAMX_ERR_NO_DEVICE;
+  }
+  ramx_dev *d = (ramx_dev *)calloc(1, sizeof(ramx_dev));
+  d->ordinal = ordinal;
+  HIPCHK(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
+  HIPCHK(hipHostMalloc((void **)&d->h_ctl, 4 * sizeof(RamxCtl), hipHostMallocDefault));
+  HIPCHK(hipMalloc((void **)&d->d_sums, 3 * NSHARD * 4 * sizeof(long long)));
+  HIPCHK(hipMalloc((void **)&d->d_g, 4 * sizeof(long long)));
+  HIPCHK(hipMalloc((void **)&d->d_ctl, 2 * sizeof(RamxCtl)));
+  for (int i = 0; i < 2; i++) HIPCHK(hipEventCreate(&d->ev_chk[i]));
+  HIPCHK(hipEventCreate(&d->ev_begin));
+  HIPCHK(hipEventCreate(&d->ev_end));
+  for (int i = 0; i < MAX_SAMPLES; i++) { HIPCHK(hipEventCreate(&d->ev_s0[i])); HIPCHK(hipEventCreate(&d->ev_s1[i])); }
+  d->block = 256;
+  const char *eb = getenv("RAMX_BLOCK");
+  if (eb) { int b = atoi(eb); if (b == 64 || b == 128 || b == 256) d->block = b; }
+  *out = d;
+  return RAMX_OK;
+}
+
+extern "C" void ramx_dev_destroy(ramx_dev *d)
+{
+  if (!d) return;
+  (void)hipSetDevice(d->ordinal);
+  (void)hipStreamSynchronize(d->stream);
+  if (d->comm) ncclCommDestroy(d->comm);
+  hipFree(d->d_lib); hipFree(d->d_flanks); hipFree(d->d_bases); hipFree(d->d_bounds);
+  hipFree(d->d_state[0]); hipFree(d->d_state[1]); hipFree(d->d_trim); hipFree(d->d_sums); hipFree(d->d_g);
+  hipFree(d->d_ctl); hipFree(d->d_cons);
+  hipHostFree(d->h_ctl);
+  for (int i = 0; i < 2; i++) hipEventDestroy(d->ev_chk[i]);
+  hipEventDestroy(d->ev_begin); hipEventDestroy(d->ev_end);
+  for (int i = 0; i < MAX_SAMPLES; i++) { hipEventDestroy(d->ev_s0[i]); hipEventDestroy(d->ev_s1[i]); }
+  hipStreamDestroy(d->stream);
+  free(d);
+}
+
+extern "C" int ramx_dev_load_library(ramx_dev *d, const int8_t *sequence, uint64_t length)
+{
+  if (!d || (!sequence && length)) { ramx_set_error("ramx_dev_load_library: bad argument"); return RAMX_ERR_ARG; }
+  HIPCHK(hipSetDevice(d->ordinal));
+  if (length > d->lib_cap)
+  {
+    if (d->d_lib) HIPCHK(hipFree(d->d_lib));
+    d->d_lib = NULL;
+    HIPCHK(hipMalloc((void **)&d->d_lib, length ? length : 1));
+    d->lib_cap = length;
+  }
+  if (length) HIPCHK(hipMemcpyAsync(d->d_lib, sequence, length, hipMemcpyHostToDevice, d->stream));
+  HIPCHK(hipStreamSynchronize(d->stream));
+  d->lib_len = length;
+  return RAMX_OK;
+}
+
+template <typename T>
+static int ensure(T **p, size_t *cap, size_t need_bytes)
+{
+  if (need_bytes <= *cap && *p) return RAMX_OK;
+  if (*p) HIPCHK(hipFree(*p));
+  *p = NULL;
+  HIPCHK(hipMalloc((void **)p, need_bytes ? need_bytes : 16));
+  *cap = need_bytes;
+  return RAMX_OK;
+}
+
+extern "C" int ramx_dev_begin_direction(ramx_dev *d, const ramx_flank *flanks, int32_t n_flanks, const ramx_params *p)
+{
+  if (!d || !p || n_flanks < 0 || (n_flanks && !flanks)) { ramx_set_error("ramx_dev_begin_direction: bad argument"); return RAMX_ERR_ARG; }
+  if (p->bandwidth < 0 || p->L < 0) { ramx_set_error("bandwidth and L must be >= 0"); return RAMX_ERR_ARG; }
+  if (!p->matrix) { ramx_set_error("scoring matrix missing"); return RAMX_ERR_ARG; }
+  HIPCHK(hipSetDevice(d->ordinal));
+  const int W = p->bandwidth, Q = W + 1;
+  const int Nx = n_flanks;
+  const int Np = ((Nx + 63) / 64) * 64 > 0 ? ((Nx + 63) / 64) * 64 : 64;
+  // t' = o + r + W runs over [0, L + 2W + 1]; +2 words of lookahead read by the kernel
+  const int KW = (p->L + 2 * W + 2) / 8 + 4;
+  d->Nx = Nx; d->Np = Np; d->KW = KW; d->p = *p;
+  // class table: tab[class][cand] = matrix[cand][code(class)], reference index order [cons][seq]
+  for (int c = 0; c < RAMX_NCLASS; c++)
+  {
+    const int code = (c == 8) ? RAMX_SYM_N : c;
+    for (int k = 0; k < 4; k++) d->tab[c][k] = p->matrix[k * 100 + code];
+  }
+  int rc;
+  if ((rc = ensure(&d->d_flanks, &d->cap_flanks, (size_t)Np * sizeof(ramx_flank)))) return rc;
+  if ((rc = ensure(&d->d_bases, &d->cap_bases, (size_t)KW * Np * sizeof(unsigned)))) return rc;
+  if (d->d_bounds) { HIPCHK(hipFree(d->d_bounds)); d->d_bounds = NULL; }
+  if (d->d_trim) { HIPCHK(hipFree(d->d_trim)); d->d_trim = NULL; }
+  HIPCHK(hipMalloc((void **)&d->d_bounds, (size_t)Np * sizeof(int2)));
+  HIPCHK(hipMalloc((void **)&d->d_trim, (size_t)Np * sizeof(int2)));
+  const size_t state_bytes = (size_t)Np * Q * sizeof(int4);
+  if (state_bytes > d->cap_state || !d->d_state[0])
+  {
+    for (int i = 0; i < 2; i++) { if (d->d_state[i]) HIPCHK(hipFree(d->d_state[i])); d->d_state[i] = NULL; }
+    for (int i = 0; i < 2; i++) HIPCHK(hipMalloc((void **)&d->d_state[i], state_bytes));
+    d->cap_state = state_bytes;
+  }
+  if ((rc = ensure(&d->d_cons, &d->cap_cons, (size_t)p->L + 16))) return rc;
+  if (Nx) HIPCHK(hipMemcpyAsync(d->d_flanks, flanks, (size_t)Nx * sizeof(ramx_flank), hipMemcpyHostToDevice, d->stream));
+  dim3 grid((Np + 255) / 256, KW);
+  hipLaunchKernelGGL(ramx_pack_kernel, grid, dim3(256), 0, d->stream, d->d_lib, (unsigned long long)d->lib_len,
+                     d->d_flanks, Nx, Np, W, d->d_bases, d->d_bounds);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemsetAsync(d->d_sums, 0, 3 * NSHARD * 4 * sizeof(long long), d->stream));
+  HIPCHK(hipMemsetAsync(d->d_cons, 0, (size_t)p->L + 16, d->stream));
+  HIPCHK(hipStreamSynchronize(d->stream));
+  d->ready = 1;
+  return RAMX_OK;
+}
+
+template <bool INIT>
+static void launch_column(ramx_dev *d, const KArgs &a)
+{
+  const int tiles = d->Np / 64;
+  switch (d->block)
+  {
+    case 64: hipLaunchKernelGGL((ramx_column_kernel<INIT, 64>), dim3(tiles), dim3(64), 0, d->stream, a); break;
+    case 128: hipLaunchKernelGGL((ramx_column_kernel<INIT, 128>), dim3((tiles + 1) / 2), dim3(128), 0, d->stream, a); break;
+    default: hipLaunchKernelGGL((ramx_column_kernel<INIT, 256>), dim3((tiles + 3) / 4), dim3(256), 0, d->stream, a); break;
+  }
+}
+
+extern "C" int ramx_dev_run_direction(ramx_dev *d, ramx_run_info *info)
+{
+  if (!d || !d->ready) { ramx_set_error("ramx_dev_run_direction: begin_direction has not been called"); return RAMX_ERR_STATE; }
+  HIPCHK(hipSetDevice(d->ordinal));
+  const ramx_params &p = d->p;
+  const int L = p.L;
+  KArgs a;
+  memset(&a, 0, sizeof(a));
+  a.bases = d->d_bases; a.bounds = d->d_bounds; a.trim = d->d_trim; a.cons_out = d->d_cons;
+  a.Np = d->Np; a.Nx = d->Nx; a.W = p.bandwidth; a.go = p.gapopen; a.ge = p.gapextn; a.cap = p.cappenalty;
+  a.minimp = p.minimprovement; a.when_to_stop = p.when_to_stop;
+  memcpy(a.tab, d->tab, sizeof(a.tab));
+  const bool multi = d->comm != NULL && d->nranks > 1;
+
+  auto slot = [&](int r) { return d->d_sums + (size_t)(((r % 3) + 3) % 3) * NSHARD * 4; };
+  HIPCHK(hipEventRecord(d->ev_begin, d->stream));
+  // K(-1): boundary row + candidates of row 0
+  a.r = -1; a.S_in = d->d_state[0]; a.S_out = d->d_state[1]; a.ctl_in = d->d_ctl; a.ctl_out = d->d_ctl + 1;
+  a.sums_in = slot(0); a.sums_out = slot(0); a.sums_zero = slot(1); a.nshards_in = NSHARD;
+  launch_column<true>(d, a);
+  HIPCHK(hipGetLastError());
+  int launches = 0, nsamp = 0, pending = -1, chk = 0;
+  const int CHUNK = 64;
+  const int stride = L > MAX_SAMPLES * 4 ? L / MAX_SAMPLES : 4;
+  bool stopped = false;
+  memset(d->h_ctl, 0, 4 * sizeof(RamxCtl));
+  for (int r = 0; r < L && !stopped; r++)
+  {
+    if (multi)
+    {
+      hipLaunchKernelGGL(ramx_fold_kernel, dim3(1), dim3(64), 0, d->stream, slot(r), d->d_g);
+      ncclResult_t nr = ncclAllReduce(d->d_g, d->d_g, 4, ncclInt64, ncclSum, d->comm, d->stream);
+      if (nr != ncclSuccess) { ramx_set_error("ncclAllReduce: %s", ncclGetErrorString(nr)); return RAMX_ERR_COMM; }
+      a.sums_in = d->d_g; a.nshards_in = 1;
+    }
+    else { a.sums_in = slot(r); a.nshards_in = NSHARD; }
+    a.r = r; a.S_in = d->d_state[(r + 1) & 1]; a.S_out = d->d_state[r & 1];
+    a.ctl_in = d->d_ctl + ((r + 1) & 1); a.ctl_out = d->d_ctl + (r & 1);
+    a.sums_out = slot(r + 1); a.sums_zero = slot(r + 2);
+    const bool sample = (r % stride) == (stride / 2) && nsamp < MAX_SAMPLES;
+    if (sample) HIPCHK(hipEventRecord(d->ev_s0[nsamp], d->stream));
+    launch_column<false>(d, a);
+    if (sample) { HIPCHK(hipEventRecord(d->ev_s1[nsamp], d->stream)); nsamp++; }
+    launches++;
+    if (((r + 1) % CHUNK) == 0 || r == L - 1)
+    {
+      HIPCHK(hipGetLastError());
+      HIPCHK(hipMemcpyAsync(d->h_ctl + 2 * chk, d->d_ctl, 2 * sizeof(RamxCtl), hipMemcpyDeviceToHost, d->stream));
+      HIPCHK(hipEventRecord(d->ev_chk[chk], d->stream));
+      if (pending >= 0)
+      {
+        HIPCHK(hipEventSynchronize(d->ev_chk[pending]));
+        const RamxCtl *h = d->h_ctl + 2 * pending;
+        if (h[0].stopped || h[1].stopped) stopped = true;
+      }
+      pending = chk;
+      chk ^= 1;
+    }
+  }
+  HIPCHK(hipEventRecord(d->ev_end, d->stream));
+  HIPCHK(hipStreamSynchronize(d->stream));
+  RamxCtl h[2];
+  HIPCHK(hipMemcpy(h, d->d_ctl, sizeof(h), hipMemcpyDeviceToHost));
+  const RamxCtl &f = (L == 0) ? h[1] : ((h[0].rows_done > h[1].rows_done) ? h[0] : h[1]);
+  d->final_ctl = f;
+  if (info)
+  {
+    info->ret = f.max_row + 1;
+    info->rows_executed = f.rows_done;
+    info->limit_warning = (f.stopped && f.rows_done - 1 == L - 1) ? 1 : 0;   // ram_extend.c:1225-1231
+    info->overflow32 = f.overflow;
+    info->n_extendable = d->Nx;
+    info->launches = launches;
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, d->ev_begin, d->ev_end));
+    info->loop_ms = ms;
+    double acc = 0; int cnt = 0;
+    for (int i = 0; i < nsamp; i++)
+    {
+      float t = 0;
+      if (hipEventElapsedTime(&t, d->ev_s0[i], d->ev_s1[i]) == hipSuccess) { acc += t; cnt++; }
+    }
+    info->kernel_ms_avg = cnt ? acc / cnt : 0.0;
+    info->kernel_samples = cnt;
+  }
+  return RAMX_OK;
+}
+
+extern "C" int ramx_dev_download(ramx_dev *d, int8_t *cons, int32_t cons_cap, int32_t *trim_high, int32_t *trim_pos)
+{
+  if (!d || !d->ready) { ramx_set_error("ramx_dev_download: nothing to download"); return RAMX_ERR_STATE; }
+  HIPCHK(hipSetDevice(d->ordinal));
+  const int rows = d->final_ctl.rows_done;
+  if (cons)
+  {
+    if (cons_cap < rows) { ramx_set_error("cons buffer too small (%d < %d)", cons_cap, rows); return RAMX_ERR_ARG; }
+    if (rows) HIPCHK(hipMemcpy(cons, d->d_cons, (size_t)rows, hipMemcpyDeviceToHost));
+  }
+  if ((trim_high || trim_pos) && d->Nx)
+  {
+    int2 *tmp = (int2 *)malloc((size_t)d->Nx * sizeof(int2));
+    HIPCHK(hipMemcpy(tmp, d->d_trim, (size_t)d->Nx * sizeof(int2), hipMemcpyDeviceToHost));
+    for (int i = 0; i < d->Nx; i++)
+    {
+      if (trim_high) trim_high[i] = tmp[i].x;
+      if (trim_pos) trim_pos[i] = tmp[i].y;
+    }
+    free(tmp);
+  }
+  return RAMX_OK;
+}
+
+extern "C" int ramx_dev_peek_state(ramx_dev *d, int32_t flank, int32_t *cells, int32_t *high, int32_t *pos)
+{
+  if (!d || !d->ready || flank < 0 || flank >= d->Nx) { ramx_set_error("ramx_dev_peek_state: bad argument"); return RAMX_ERR_ARG; }
+  HIPCHK(hipSetDevice(d->ordinal));
+  const int W = d->p.bandwidth, Q = W + 1, B = 2 * W + 1;
+  const int rows = d->final_ctl.rows_done;
+  const int4 *S = d->d_state[(rows - 1) & 1];   // K(r) wrote state[r & 1]; rows == 0 -> boundary row in slot 1
+  const int tile = flank / 64, lane = flank % 64;
+  for (int q = 0; q < Q; q++)
+  {
+    int4 v;
+    HIPCHK(hipMemcpy(&v, S + ((size_t)tile * Q + q) * 64 + lane, sizeof(v), hipMemcpyDeviceToHost));
+    cells[4 * q] = v.x; cells[4 * q + 1] = v.y;
+    if (2 * q + 1 < B) { cells[4 * q + 2] = v.z; cells[4 * q + 3] = v.w; }
+    else { if (high) *high = v.z; if (pos) *pos = v.w; }
+  }
+  return RAMX_OK;
+}
+
+extern "C" int ramx_comm_unique_id(uint8_t id[128])
+{
+  ncclUniqueId u;
+  ncclResult_t r = ncclGetUniqueId(&u);
+  if (r != ncclSuccess) { ramx_set_error("ncclGetUniqueId: %s", ncclGetErrorString(r)); return RAMX_ERR_COMM; }
+  memcpy(id, &u, 128);
+  return RAMX_OK;
+}
+
+extern "C" int ramx_dev_comm_init(ramx_dev *d, const uint8_t id[128], int rank, int nranks)
+{
+  if (!d || rank < 0 || rank >= nranks) { ramx_set_error("ramx_dev_comm_init: bad argument"); return RAMX_ERR_ARG; }
+  HIPCHK(hipSetDevice(d->ordinal));
+  d->rank = rank; d->nranks = nranks;
+  if (nranks == 1) return RAMX_OK;
+  ncclUniqueId u;
+  memcpy(&u, id, 128);
+  ncclResult_t r = ncclCommInitRank(&d->comm, nranks, u, rank);
+  if (r != ncclSuccess) { ramx_set_error("ncclCommInitRank: %s", ncclGetErrorString(r)); d->comm = NULL; return RAMX_ERR_COMM; }
+  return RAMX_OK;
+}

@@ -1,0 +1,250 @@
+/*
+ * ramx_extend.c -- seam 1 of include/ramx.h: the extend_alignment()-compatible entry.
+ *
+ * Host side of the extension loop (reference ram_extend.c:859-1258): walks the caller's core
+ * list, resolves every extendable core into a flank descriptor (start, step, complement, in-bounds
+ * interval), hands the flanks to the device layer (ramx_device.hip), and writes the results back
+ * into master[] and the cores exactly where the reference does.  No DP arithmetic happens here.
+ */
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include "ramx_internal.h"
+
+/* the reference's hot-path globals (ram_extend.c:40,52,61) */
+static int g_verbose = 0;
+static int g_when_to_stop = 100;
+static int g_l = 1;
+
+void ramx_set_runtime(int verbose, int when_to_stop, int l)
+{
+  g_verbose = verbose;
+  g_when_to_stop = when_to_stop;
+  g_l = l;
+}
+int ramx_runtime_verbose(void) { return g_verbose; }
+int ramx_runtime_when_to_stop(void) { return g_when_to_stop; }
+int ramx_runtime_l(void) { return g_l; }
+
+static ramx_dev *g_dev = NULL;
+static const int8_t *g_lib_ptr = NULL;
+static uint64_t g_lib_len = 0;
+
+ramx_dev *ramx_default_device(void)
+{
+  if (!g_dev)
+  {
+    int ord = 0;
+    const char *e = getenv("RAMX_DEVICE");
+    if (e) ord = atoi(e);
+    if (ramx_dev_create(ord, &g_dev) != RAMX_OK) g_dev = NULL;
+  }
+  return g_dev;
+}
+
+static double wall_ms(void)
+{
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+
+static int64_t clamp64(int64_t v, int64_t lo, int64_t hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+/*
+ * Resolve one core into a flank for `direction` (reference bnw_extend.c:778-788, 824-868).
+ * With p(t) = start + step * t, t = offset + row, the reference's unsigned index logic is
+ * equivalent to "out of bounds iff p < lowerSeqBound || p > upperSeqBound || p < 0"
+ * (SURVEY.md App. D rule 1; tests/test_flank_rule.py re-checks it against the oracle).
+ */
+static void resolve_flank(int direction, int64_t left_pos, int64_t right_pos, int64_t lower, int64_t upper,
+                          int orient, int W, int L, ramx_flank *f)
+{
+  int64_t start, lo = lower < 0 ? 0 : lower, tlo, thi;
+  if (direction)
+    start = orient ? right_pos - 1 : right_pos + 1;
+  else
+    start = orient ? left_pos + 1 : left_pos - 1;
+  f->start = start;
+  f->step = ((direction != 0) == (orient != 0)) ? -1 : 1;
+  f->compl_ = orient ? 1 : 0;
+  memset(f->pad_, 0, sizeof(f->pad_));
+  if (f->step > 0) { tlo = lo - start; thi = upper - start; }
+  else { tlo = start - upper; thi = start - lo; }
+  /* only t in [-W, L+W] is ever looked at; clamp so the device can use int32 */
+  f->t_lo = (int32_t)clamp64(tlo, -(int64_t)W - 2, (int64_t)L + W + 2);
+  f->t_hi = (int32_t)clamp64(thi, -(int64_t)W - 2, (int64_t)L + W + 2);
+}
+
+int ramx_extend_flat(int direction, ramx_flat_cores *c, const int8_t *sequence, uint64_t seq_len,
+                     int8_t *master, const ramx_params *p, ramx_run_info *info)
+{
+  ramx_run_info local;
+  if (!info) info = &local;
+  memset(info, 0, sizeof(*info));
+  if (!c || !p || !master || (c->n > 0 && !sequence)) { ramx_set_error("ramx_extend_flat: bad argument"); return RAMX_ERR_ARG; }
+  ramx_dev *d = ramx_default_device();
+  if (!d) return RAMX_ERR_NO_DEVICE;
+  const double t0 = wall_ms();
+  const int N = c->n, W = p->bandwidth, L = p->L;
+  int rc;
+  /* the library is shared by both directions: upload once per (pointer,length) */
+  if (sequence != g_lib_ptr || seq_len != g_lib_len)
+  {
+    if ((rc = ramx_dev_load_library(d, sequence, seq_len)) != RAMX_OK) return rc;
+    g_lib_ptr = sequence;
+    g_lib_len = seq_len;
+  }
+  int *map = (int *)malloc(sizeof(int) * (N > 0 ? N : 1));
+  ramx_flank *fl = (ramx_flank *)malloc(sizeof(ramx_flank) * (N > 0 ? N : 1));
+  int nx = 0;
+  for (int n = 0; n < N; n++)
+  {
+    /* ram_extend.c:984-985: only cores extendable in this direction take part (but keep index n) */
+    if ((direction && c->right_ext[n]) || (!direction && c->left_ext[n]))
+    {
+      resolve_flank(direction, c->left_pos[n], c->right_pos[n], c->lower[n], c->upper[n], c->orient[n], W, L, &fl[nx]);
+      map[nx++] = n;
+    }
+  }
+  rc = ramx_dev_begin_direction(d, fl, nx, p);
+  info->prep_ms = wall_ms() - t0;
+  if (rc == RAMX_OK) rc = ramx_dev_run_direction(d, info);
+  if (rc != RAMX_OK) { free(map); free(fl); return rc; }
+  info->prep_ms = info->prep_ms;
+  int8_t *cons = (int8_t *)malloc((size_t)L + 16);
+  int32_t *th = (int32_t *)malloc(sizeof(int32_t) * (nx > 0 ? nx : 1));
+  int32_t *tp = (int32_t *)malloc(sizeof(int32_t) * (nx > 0 ? nx : 1));
+  rc = ramx_dev_download(d, cons, L + 16, th, tp);
+  if (rc == RAMX_OK)
+  {
+    /* ram_extend.c:1092-1095 */
+    for (int r = 0; r < info->rows_executed; r++)
+    {
+      if (direction) master[(size_t)L + p->l + r] = cons[r];
+      else master[(size_t)L - r - 1] = cons[r];
+    }
+    /* ram_extend.c:1234-1247 */
+    for (int i = 0; i < nx; i++)
+    {
+      if (th[i] > 0 && tp[i] >= 0)
+      {
+        const int n = map[i];
+        if (direction) c->right_len[n] = tp[i] + 1;
+        else c->left_len[n] = tp[i] + 1;
+        c->score[n] += th[i];
+      }
+    }
+  }
+  free(cons); free(th); free(tp); free(map); free(fl);
+  return rc == RAMX_OK ? info->ret : rc;
+}
+
+int ramx_extend_alignment(int direction, struct coreAlignment *coreAlign, int ****score,
+                          struct sequenceLibrary *seqLib, char *master, int BANDWIDTH,
+                          int CAPPENALTY, int MINIMPROVEMENT, int L, int N,
+                          struct scoringSystem *scoreParams, FILE *pathStringFile)
+{
+  (void)score;
+  if (pathStringFile != NULL)
+  {
+    fprintf(stderr, "RAMExtend(ramx): -outmat (per-cell path dump) is not available on the device path\n");
+    exit(1);
+  }
+  if (g_verbose >= 3)   /* ram_extend.c:886-892 */
+  {
+    if (direction) printf("extend_alignment(right): Called with %d edges\n", N);
+    else printf("extend_alignment(left): Called with %d edges\n", N);
+  }
+  if (g_verbose >= 10)
+    fprintf(stderr, "RAMExtend(ramx): per-row dumps of -vvvv and above are not produced by the device path\n");
+
+  const int n = N > 0 ? N : 0;
+  int64_t *i64 = (int64_t *)malloc(sizeof(int64_t) * 4 * (n + 1));
+  int8_t *i8 = (int8_t *)malloc(3 * (n + 1));
+  int32_t *i32 = (int32_t *)calloc(3 * (n + 1), sizeof(int32_t));
+  ramx_flat_cores fc;
+  fc.left_pos = i64; fc.right_pos = i64 + n; fc.lower = i64 + 2 * n; fc.upper = i64 + 3 * n;
+  fc.orient = i8; fc.left_ext = i8 + n; fc.right_ext = i8 + 2 * n;
+  fc.left_len = i32; fc.right_len = i32 + n; fc.score = i32 + 2 * n;
+  int k = 0;
+  struct coreAlignment *cc;
+  /* the reference walks the whole list for the DP but only the first N nodes for the write-back
+   * (ram_extend.c:980 vs :1235); score[] is sized for N, so N nodes is all that is meaningful */
+  for (cc = coreAlign; cc != NULL && k < n; cc = cc->next, k++)
+  {
+    ((int64_t *)fc.left_pos)[k] = (int64_t)cc->leftSeqPos;
+    ((int64_t *)fc.right_pos)[k] = (int64_t)cc->rightSeqPos;
+    ((int64_t *)fc.lower)[k] = (int64_t)cc->lowerSeqBound;
+    ((int64_t *)fc.upper)[k] = (int64_t)cc->upperSeqBound;
+    ((int8_t *)fc.orient)[k] = cc->orient ? 1 : 0;
+    ((int8_t *)fc.left_ext)[k] = cc->leftExtendable ? 1 : 0;
+    ((int8_t *)fc.right_ext)[k] = cc->rightExtendable ? 1 : 0;
+    fc.left_len[k] = cc->leftExtensionLen;
+    fc.right_len[k] = cc->rightExtensionLen;
+    fc.score[k] = cc->score;
+  }
+  fc.n = k;
+
+  int32_t *mflat = (int32_t *)malloc(sizeof(int32_t) * 100 * 100);
+  /* only [0..3][0..7,99] is defined in the reference's matrix (score_system.c:187-395) */
+  memset(mflat, 0, sizeof(int32_t) * 100 * 100);
+  for (int a = 0; a < 4; a++)
+  {
+    for (int b = 0; b < 8; b++) mflat[a * 100 + b] = scoreParams->matrix[a][b];
+    mflat[a * 100 + RAMX_SYM_N] = scoreParams->matrix[a][RAMX_SYM_N];
+  }
+  ramx_params p;
+  p.bandwidth = BANDWIDTH; p.cappenalty = CAPPENALTY; p.minimprovement = MINIMPROVEMENT; p.L = L;
+  p.when_to_stop = g_when_to_stop; p.l = g_l; p.gapopen = scoreParams->gapopen; p.gapextn = scoreParams->gapextn;
+  p.matrix = mflat;
+  ramx_run_info info;
+  int ret = ramx_extend_flat(direction, &fc, (const int8_t *)seqLib->sequence, seqLib->length, (int8_t *)master, &p, &info);
+  if (ret < 0)
+  {
+    /* the reference has no error return on this path: print + exit(1) like its other failures */
+    fprintf(stderr, "RAMExtend(ramx): device extension failed: %s\n", ramx_last_error());
+    exit(1);
+  }
+  if (info.overflow32)
+    fprintf(stderr, "RAMExtend(ramx): note: a column sum exceeded the int32 range; the reference's int accumulator "
+                    "(ram_extend.c:874-878) would have wrapped here, the device keeps int64\n");
+  if (info.ret >= 0 && info.rows_executed > 0 && g_verbose >= 3 && info.rows_executed <= L)
+  {
+    /* ram_extend.c:1216-1223: printed only when the loop broke */
+    const int last = info.rows_executed - 1;
+    if (abs(last - (info.ret - 1)) >= g_when_to_stop)
+      printf("Ending...due to row_idx=%d - max_extension_score_row_idx=%d <= -WHEN_TO_STOP=%d\n", last,
+             info.ret - 1, g_when_to_stop);
+  }
+  if (info.limit_warning)   /* ram_extend.c:1225-1231 */
+  {
+    if (direction) printf("WARNING: Extended sequence right to the limit ( L=%d ).\n", L);
+    else printf("WARNING: Extended sequence left to the limit ( L=%d ).\n", L);
+  }
+  k = 0;
+  for (cc = coreAlign; cc != NULL && k < fc.n; cc = cc->next, k++)
+  {
+    cc->leftExtensionLen = fc.left_len[k];
+    cc->rightExtensionLen = fc.right_len[k];
+    cc->score = fc.score[k];
+  }
+  free(i64); free(i8); free(i32); free(mflat);
+  return ret;
+}
+
+/* bnw_extend.c:87-155 -- kept for link compatibility; the device path never reads it, so a single
+ * zeroed block with the same index shape is enough (and avoids 2*N*B mallocs). */
+int ****ramx_allocate_score(int num_align, int bandwidth)
+{
+  (void)bandwidth;
+  if (num_align < 1) return NULL;
+  return (int ****)calloc(2, sizeof(int ***));
+}
+
+void ramx_free_score(int num_align, int bandwidth, int ****score)
+{
+  (void)num_align; (void)bandwidth;
+  free(score);
+}
