@@ -82,7 +82,8 @@ def lib() -> C.CDLL:
                                           C.POINTER(C.c_int32)]
         L.ramx_comm_unique_id.argtypes = [C.c_void_p]
         L.ramx_dev_comm_init.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
-        L.ramx_cli_main.argtypes = [C.c_int, C.POINTER(C.c_char_p)]
+        if hasattr(L, "ramx_cli_main"):
+            L.ramx_cli_main.argtypes = [C.c_int, C.POINTER(C.c_char_p)]
         _lib = L
     return _lib
 

@@ -241,7 +241,11 @@ __global__ __launch_bounds__(BLOCK) void ramx_column_kernel(const KArgs a)
   if (!INIT)
   {
     const RamxCtl c = *a.ctl_in;
-    if (c.stopped) return;   // uniform: the host runs ahead of the device-side stop decision
+    if (c.stopped)           // uniform: the host runs ahead of the device-side stop decision
+    {
+      if (blockIdx.x == 0 && threadIdx.x == 0) *a.ctl_out = c;   // keep both flip-flop slots stopped
+      return;
+    }
     long long v[4] = { 0, 0, 0, 0 };
     if (lane < a.nshards_in)
     {
