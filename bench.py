@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""bench.py -- RAMExtend extension loop on MI355X: flank-bp aligned / s (= extension columns/s x flanks).
+
+Workload (BASELINE.json configs[2] / configs[3]): synthetic N = 100,000 flanks per GPU x L = 10,000 bp,
+bandwidth 40, matrix 14p43g, shared 1,500 bp ancestor at 14 % divergence, -stopafter L so that all L
+columns of the right extension are executed.  One "step" = one full pass of the extension loop
+(ramx_dev_run_direction: L column launches) over the flank set already resident in HBM.
+
+N > 1: one process per GPU (torch.distributed launcher), flanks sharded over ranks (weak scaling:
+100,000 flanks per rank), one 4 x int64 RCCL all-reduce per column inside libramx.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+from repeatafterme_amd import _lib  # noqa: E402  (loads libramx before torch: see DESIGN.md "runtime")
+from repeatafterme_amd.datamodel import ExtendParams  # noqa: E402
+from repeatafterme_amd.device import Device, resolve_flanks  # noqa: E402
+from repeatafterme_amd.scoring import get_matrix  # noqa: E402
+from repeatafterme_amd.synth import synth_family  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def algorithmic_bytes_per_flank_column(W: int) -> float:
+    """read prev row + write curr row + 1/4 B base + 16 B (high,pos)."""
+    B = 2 * W + 1
+    return 16.0 * B + 16.25
+
+
+def cpu_baseline(fs, p: ExtendParams, n_sample: int, cols: int):
+    """Times the reference (oracle/_ref) or, failing that, the oracle port, single-threaded."""
+    from oracle import pyoracle as po
+    from repeatafterme_amd.datamodel import new_master
+    sub = fs.cores.subset(slice(0, n_sample))
+    hi = int(sub.upper.max()) + 1
+    seq = fs.sequence[:hi]
+    pp = po.Params(bandwidth=p.bandwidth, cappenalty=p.cappenalty, minimprovement=p.minimprovement, L=cols,
+                   when_to_stop=cols, l=1, gapopen=p.gapopen, gapextn=p.gapextn, matrix=p.matrix)
+    m = new_master(cols)
+    kind = "reference" if po.have_ref() else "port"
+    t0 = time.perf_counter()
+    if kind == "reference":
+        devnull = os.open(os.devnull, os.O_WRONLY)
+        saved = os.dup(1)
+        os.dup2(devnull, 1)     # the reference prints its limit warning on stdout
+        try:
+            r = po.ref_extend(1, sub, seq, m, pp)
+        finally:
+            os.dup2(saved, 1)
+            os.close(devnull)
+            os.close(saved)
+        rows = cols
+    else:
+        r = po.oracle_extend(1, sub, seq, m, pp)
+        rows = r.rows_executed
+    dt = time.perf_counter() - t0
+    return {"value": rows * n_sample / dt, "unit": "flank-bp/s", "cores": 1, "kind": kind,
+            "sample": f"first {n_sample} flanks of the same set, {rows} columns, right extension, "
+                      f"W={p.bandwidth}, single thread, {dt:.1f} s",
+            "columns_per_sec_at_sample_N": rows / dt}, m, sub
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--flanks", type=int, default=100000, help="flanks per GPU")
+    ap.add_argument("--L", type=int, default=10000)
+    ap.add_argument("--bandwidth", type=int, default=40)
+    ap.add_argument("--cpu-flanks", type=int, default=20000)
+    ap.add_argument("--cpu-cols", type=int, default=200)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    W, L, N = args.bandwidth, args.L, args.flanks
+    mat, go, ge = get_matrix("14p43g")
+    p = ExtendParams(bandwidth=W, cappenalty=-90, minimprovement=27, L=L, when_to_stop=L, l=1,
+                     gapopen=go, gapextn=ge, matrix=mat, matrix_name="14p43g")
+    t0 = time.time()
+    fs = synth_family(N, L, W, K=1500, seed=1 + rank)   # each rank: its own shard of the family
+    t_gen = time.time() - t0
+
+    dev = Device(local_rank)
+    if world > 1:
+        uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            uid = torch.from_numpy(dev.unique_id().copy()).cuda()
+        dist.broadcast(uid, 0)
+        dev.comm_init(uid.cpu().numpy(), rank, world)
+    t0 = time.time()
+    dev.load_library(fs.sequence)
+    flanks, idx = resolve_flanks(1, fs.cores, W, L)
+    dev.begin_direction(flanks, p)
+    t_upload = time.time() - t0
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    infos = []
+    for _ in range(args.warmup):
+        dev.begin_direction(flanks, p)
+        dev.run_direction()
+    dev.begin_direction(flanks, p)
+    barrier()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        if s:
+            dev.reset_direction()
+        infos.append(dev.run_direction())
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    cols = sum(i.rows_executed for i in infos)
+    total_flanks = N * world
+    value = cols * total_flanks / dt
+    kavg_ms = float(np.mean([i.kernel_ms_avg for i in infos]))
+    loop_ms = float(np.mean([i.loop_ms for i in infos]))
+    abytes = algorithmic_bytes_per_flank_column(W) * N          # per launch, per GPU
+    achieved = abytes / (kavg_ms * 1e-3) / 1e9 if kavg_ms > 0 else 0.0
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
+    if os.path.exists(pmc):
+        try:
+            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    out = {
+        "metric": "flank_bp_aligned_per_sec (extension columns/s x flanks)", "value": value, "unit": "flank-bp/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+        "config": {"workload": f"synthetic N={N} flanks/GPU x L={L} bp, bandwidth={W}, matrix 14p43g, "
+                               f"K=1500 @14% divergence, right extension, stopafter=L (all L columns)",
+                   "flanks_total": total_flanks, "columns_per_step": cols // max(args.steps, 1),
+                   "parallelism": f"flank-sharded x{world}, 4xint64 all-reduce per column" if world > 1 else "single GPU"},
+        "columns_per_sec": cols / dt,
+        "cell_updates_per_sec": cols / dt * total_flanks * (2 * W + 1) * 4,
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "kernel": "ramx_column_kernel<false,256>", "kernel_avg_us": kavg_ms * 1e3,
+                     "loop_avg_us_per_column": loop_ms * 1e3 / max(infos[0].rows_executed, 1),
+                     "algorithmic_bytes_per_launch": abytes, "samples": int(sum(i.kernel_samples for i in infos))},
+        "setup": {"synth_s": t_gen, "upload_pack_s": t_upload},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu:
+        cb, m_cpu, sub = cpu_baseline(fs, p, min(args.cpu_flanks, N), args.cpu_cols)
+        out["cpu_baseline"] = cb
+        out["gpu_over_cpu"] = value / cb["value"]
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    dev.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -172,6 +172,12 @@ typedef struct ramx_flank
   int8_t  pad_[6];
 } ramx_flank;
 
+/* Host-side resolution of the cores that are extendable in `direction` into flank descriptors
+ * (reference bnw_extend.c:778-788,824-868).  flanks / core_index must hold cores->n entries;
+ * core_index[i] is the position in the core list of flank i.  Returns the number of flanks. */
+int ramx_resolve_flanks(int direction, const ramx_flat_cores *cores, int bandwidth, int L,
+                        ramx_flank *flanks, int32_t *core_index);
+
 /* upload (per direction): flank descriptors -> HBM, pack kernel builds the transposed 4-bit
  * windows, DP state / vote / control buffers are (re)initialised. */
 int ramx_dev_begin_direction(ramx_dev *d, const ramx_flank *flanks, int32_t n_flanks, const ramx_params *p);

@@ -11,7 +11,7 @@ CLI_PATH = os.path.join(_PKG, "RAMExtend")
 
 # every symbol include/ramx.h declares (tests/test_cabi.py checks the .so exports all of them)
 EXPORTS = [
-    "ramx_set_runtime", "ramx_extend_alignment", "ramx_extend_flat", "ramx_last_error", "ramx_device_count",
+    "ramx_set_runtime", "ramx_extend_alignment", "ramx_extend_flat", "ramx_resolve_flanks", "ramx_last_error", "ramx_device_count",
     "ramx_dev_create", "ramx_dev_destroy", "ramx_dev_load_library", "ramx_dev_begin_direction",
     "ramx_dev_run_direction", "ramx_dev_download", "ramx_dev_peek_state", "ramx_comm_unique_id",
     "ramx_dev_comm_init", "ramx_get_matrix", "ramx_get_matrix_using_gap_penalties",
@@ -70,6 +70,8 @@ def lib() -> C.CDLL:
         L.ramx_extend_flat.argtypes = [C.c_int, C.POINTER(FlatCores), C.c_void_p, C.c_uint64, C.c_void_p,
                                        C.POINTER(Params), C.POINTER(RunInfo)]
         L.ramx_extend_flat.restype = C.c_int
+        L.ramx_resolve_flanks.argtypes = [C.c_int, C.POINTER(FlatCores), C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.ramx_resolve_flanks.restype = C.c_int
         L.ramx_device_count.restype = C.c_int
         L.ramx_dev_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
         L.ramx_dev_destroy.argtypes = [C.c_void_p]

@@ -505,15 +505,15 @@ extern "C" void ramx_dev_destroy(ramx_dev *d)
   if (!d) return;
   (void)hipSetDevice(d->ordinal);
   (void)hipStreamSynchronize(d->stream);
-  if (d->comm) ncclCommDestroy(d->comm);
-  hipFree(d->d_lib); hipFree(d->d_flanks); hipFree(d->d_bases); hipFree(d->d_bounds);
-  hipFree(d->d_state[0]); hipFree(d->d_state[1]); hipFree(d->d_trim); hipFree(d->d_sums); hipFree(d->d_g);
-  hipFree(d->d_ctl); hipFree(d->d_cons);
-  hipHostFree(d->h_ctl);
-  for (int i = 0; i < 2; i++) hipEventDestroy(d->ev_chk[i]);
-  hipEventDestroy(d->ev_begin); hipEventDestroy(d->ev_end);
-  for (int i = 0; i < MAX_SAMPLES; i++) { hipEventDestroy(d->ev_s0[i]); hipEventDestroy(d->ev_s1[i]); }
-  hipStreamDestroy(d->stream);
+  if (d->comm) (void)ncclCommDestroy(d->comm);
+  (void)hipFree(d->d_lib); (void)hipFree(d->d_flanks); (void)hipFree(d->d_bases); (void)hipFree(d->d_bounds);
+  (void)hipFree(d->d_state[0]); (void)hipFree(d->d_state[1]); (void)hipFree(d->d_trim); (void)hipFree(d->d_sums); (void)hipFree(d->d_g);
+  (void)hipFree(d->d_ctl); (void)hipFree(d->d_cons);
+  (void)hipHostFree(d->h_ctl);
+  for (int i = 0; i < 2; i++) (void)hipEventDestroy(d->ev_chk[i]);
+  (void)hipEventDestroy(d->ev_begin); (void)hipEventDestroy(d->ev_end);
+  for (int i = 0; i < MAX_SAMPLES; i++) { (void)hipEventDestroy(d->ev_s0[i]); (void)hipEventDestroy(d->ev_s1[i]); }
+  (void)hipStreamDestroy(d->stream);
   free(d);
 }
 
@@ -617,6 +617,7 @@ extern "C" int ramx_dev_run_direction(ramx_dev *d, ramx_run_info *info)
   const bool multi = d->comm != NULL && d->nranks > 1;
 
   auto slot = [&](int r) { return d->d_sums + (size_t)(((r % 3) + 3) % 3) * NSHARD * 4; };
+  HIPCHK(hipMemsetAsync(d->d_sums, 0, 3 * NSHARD * 4 * sizeof(long long), d->stream));
   HIPCHK(hipEventRecord(d->ev_begin, d->stream));
   // K(-1): boundary row + candidates of row 0
   a.r = -1; a.S_in = d->d_state[0]; a.S_out = d->d_state[1]; a.ctl_in = d->d_ctl; a.ctl_out = d->d_ctl + 1;

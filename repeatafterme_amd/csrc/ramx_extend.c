@@ -77,6 +77,23 @@ static void resolve_flank(int direction, int64_t left_pos, int64_t right_pos, in
   f->t_hi = (int32_t)clamp64(thi, -(int64_t)W - 2, (int64_t)L + W + 2);
 }
 
+int ramx_resolve_flanks(int direction, const ramx_flat_cores *c, int bandwidth, int L, ramx_flank *flanks,
+                        int32_t *core_index)
+{
+  int nx = 0;
+  for (int n = 0; n < c->n; n++)
+  {
+    /* ram_extend.c:984-985: only cores extendable in this direction take part (but keep index n) */
+    if ((direction && c->right_ext[n]) || (!direction && c->left_ext[n]))
+    {
+      resolve_flank(direction, c->left_pos[n], c->right_pos[n], c->lower[n], c->upper[n], c->orient[n], bandwidth, L,
+                    &flanks[nx]);
+      core_index[nx++] = n;
+    }
+  }
+  return nx;
+}
+
 int ramx_extend_flat(int direction, ramx_flat_cores *c, const int8_t *sequence, uint64_t seq_len,
                      int8_t *master, const ramx_params *p, ramx_run_info *info)
 {
@@ -98,21 +115,11 @@ int ramx_extend_flat(int direction, ramx_flat_cores *c, const int8_t *sequence, 
   }
   int *map = (int *)malloc(sizeof(int) * (N > 0 ? N : 1));
   ramx_flank *fl = (ramx_flank *)malloc(sizeof(ramx_flank) * (N > 0 ? N : 1));
-  int nx = 0;
-  for (int n = 0; n < N; n++)
-  {
-    /* ram_extend.c:984-985: only cores extendable in this direction take part (but keep index n) */
-    if ((direction && c->right_ext[n]) || (!direction && c->left_ext[n]))
-    {
-      resolve_flank(direction, c->left_pos[n], c->right_pos[n], c->lower[n], c->upper[n], c->orient[n], W, L, &fl[nx]);
-      map[nx++] = n;
-    }
-  }
+  const int nx = ramx_resolve_flanks(direction, c, W, L, fl, map);
   rc = ramx_dev_begin_direction(d, fl, nx, p);
   info->prep_ms = wall_ms() - t0;
   if (rc == RAMX_OK) rc = ramx_dev_run_direction(d, info);
   if (rc != RAMX_OK) { free(map); free(fl); return rc; }
-  info->prep_ms = info->prep_ms;
   int8_t *cons = (int8_t *)malloc((size_t)L + 16);
   int32_t *th = (int32_t *)malloc(sizeof(int32_t) * (nx > 0 ? nx : 1));
   int32_t *tp = (int32_t *)malloc(sizeof(int32_t) * (nx > 0 ? nx : 1));

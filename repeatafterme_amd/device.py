@@ -1,0 +1,89 @@
+"""Thin Python handle on seam 2 of include/ramx.h (ramx_dev_*): init / upload / run_direction /
+download / destroy.  Used by bench.py and the parity tests that want to look below
+``extend_alignment`` (state peeks, repeated runs on resident data, the multi-GPU communicator)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .datamodel import CoreSet, ExtendParams
+from .extend import RunInfo, _info, _params
+
+
+def resolve_flanks(direction: int, cores: CoreSet, bandwidth: int, L: int):
+    """-> (flank descriptor array, core index of every flank); C-ABI ramx_resolve_flanks."""
+    L_ = _lib.lib()
+    fc = _lib.FlatCores(cores.n, *[getattr(cores, k).ctypes.data for k in
+                                   ("left_pos", "right_pos", "lower", "upper", "orient", "left_ext",
+                                    "right_ext", "left_len", "right_len", "score")])
+    flanks = (_lib.Flank * max(cores.n, 1))()
+    idx = np.zeros(max(cores.n, 1), np.int32)
+    nx = L_.ramx_resolve_flanks(int(direction), C.byref(fc), bandwidth, L, flanks, idx.ctypes.data)
+    return (flanks, nx), idx[:nx].copy()
+
+
+class Device:
+    def __init__(self, ordinal: int = 0):
+        self._L = _lib.lib()
+        h = C.c_void_p()
+        _lib.check(self._L.ramx_dev_create(ordinal, C.byref(h)), "ramx_dev_create")
+        self._h = h
+        self._keep = None
+        self.nx = 0
+        self.p = None
+
+    def close(self):
+        if self._h:
+            self._L.ramx_dev_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def load_library(self, sequence: np.ndarray):
+        assert sequence.dtype == np.int8 and sequence.flags.c_contiguous
+        _lib.check(self._L.ramx_dev_load_library(self._h, sequence.ctypes.data, len(sequence)), "ramx_dev_load_library")
+
+    def begin_direction(self, flanks, p: ExtendParams):
+        arr, nx = flanks
+        cp, keep = _params(p)
+        self._keep = keep
+        _lib.check(self._L.ramx_dev_begin_direction(self._h, arr, nx, C.byref(cp)), "ramx_dev_begin_direction")
+        self.nx, self.p = nx, p
+
+    def run_direction(self) -> RunInfo:
+        ci = _lib.RunInfo()
+        _lib.check(self._L.ramx_dev_run_direction(self._h, C.byref(ci)), "ramx_dev_run_direction")
+        self.last = _info(ci)
+        return self.last
+
+    def download(self):
+        rows = self.last.rows_executed
+        cons = np.zeros(max(rows, 1), np.int8)
+        th = np.zeros(max(self.nx, 1), np.int32)
+        tp = np.zeros(max(self.nx, 1), np.int32)
+        _lib.check(self._L.ramx_dev_download(self._h, cons.ctypes.data, len(cons), th.ctypes.data, tp.ctypes.data),
+                   "ramx_dev_download")
+        return cons[:rows], th[:self.nx], tp[:self.nx]
+
+    def peek_state(self, flank: int):
+        B = 2 * self.p.bandwidth + 1
+        cells = np.zeros(4 * (self.p.bandwidth + 1), np.int32)
+        hi, po = C.c_int32(), C.c_int32()
+        _lib.check(self._L.ramx_dev_peek_state(self._h, flank, cells.ctypes.data, C.byref(hi), C.byref(po)),
+                   "ramx_dev_peek_state")
+        return cells[:2 * B].reshape(B, 2).copy(), hi.value, po.value
+
+    def unique_id(self) -> np.ndarray:
+        uid = np.zeros(128, np.uint8)
+        _lib.check(self._L.ramx_comm_unique_id(uid.ctypes.data), "ramx_comm_unique_id")
+        return uid
+
+    def comm_init(self, uid: np.ndarray, rank: int, nranks: int):
+        uid = np.ascontiguousarray(uid, dtype=np.uint8)
+        _lib.check(self._L.ramx_dev_comm_init(self._h, uid.ctypes.data, rank, nranks), "ramx_dev_comm_init")
