@@ -1,0 +1,107 @@
+"""The RAMExtend executable (drop-in CLI seam) against what the reference binary printed and wrote:
+stdout, -cons, -outtsv, -outfa, for the reference's own fixture and the synthetic genomes."""
+import os
+import subprocess
+
+import pytest
+
+from repeatafterme_amd import _lib
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+CASES = sorted(os.listdir(os.path.join(G, "cli")))
+STEM = {"t2": "extension-test2", "g0": "genome_0", "g1": "genome_1", "g2": "genome_2", "g3": "genome_3", "ov": "genome_ov"}
+
+
+def _norm(txt):
+    out = []
+    for line in txt.splitlines():
+        if line.startswith("RAMExtend Version"):
+            line = "RAMExtend Version <v>"       # build id differs by design
+        if line.startswith("Program duration is"):
+            line = "Program duration is <t>"
+        out.append(line)
+    return out
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_cli_matches_reference_outputs(case, tmp_path):
+    argv = open(os.path.join(G, "cli", case, "argv")).read().split()
+    stem = STEM[case.split("_")[0]]
+    cmd = [_lib.CLI_PATH, "-twobit", f"inputs/{stem}.2bit", "-ranges", f"inputs/{stem}.tsv", "-cons", str(tmp_path / "cons"),
+           "-outtsv", str(tmp_path / "tsv"), "-outfa", str(tmp_path / "fa")] + argv
+    r = subprocess.run(cmd, cwd=G, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got = r.stdout.replace(str(tmp_path) + "/", "")
+    want = open(os.path.join(G, "cli", case, "stdout")).read()
+    assert _norm(got) == _norm(want)
+    for f in ("cons", "tsv", "fa"):
+        ref_f = os.path.join(G, "cli", case, f)
+        if os.path.exists(ref_f):
+            assert open(tmp_path / f).read() == open(ref_f).read(), f
+        else:
+            assert not os.path.exists(tmp_path / f) or f != "cons"
+
+
+def test_cli_version_and_usage():
+    r = subprocess.run([_lib.CLI_PATH, "-version"], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.startswith("RAMExtend Version 0.0.7 - build ")
+    r = subprocess.run([_lib.CLI_PATH, "-h"], capture_output=True, text=True)      # extend-stk.pl:202-208 probes this way
+    assert r.returncode == 1 and "RAMExtend Version 0.0.7" in r.stdout and "Usage:" in r.stdout
+    r = subprocess.run([_lib.CLI_PATH, "-ranges", "x", "-matrix", "nope", "-twobit", "y"], capture_output=True, text=True)
+    assert r.returncode == 1
+
+
+def test_cli_prefix_matching_quirks(tmp_path):
+    """cmd_line_opts.c: the first argv entry having the option text as a prefix wins (-gap matches -gapopen)."""
+    base = [_lib.CLI_PATH, "-twobit", "inputs/extension-test2.2bit", "-ranges", "inputs/extension-test2.tsv"]
+    a = subprocess.run(base + ["-bandw", "40", "-matrix", "14p43g"], cwd=G, capture_output=True, text=True)
+    assert a.returncode == 0 and "BANDWIDTH (bandwidth) 14" in a.stdout       # "-bandw" is NOT matched by "-bandwidth"
+    b = subprocess.run(base + ["-bandwidthXYZ", "40", "-matrix", "14p43g"], cwd=G, capture_output=True, text=True)
+    assert "BANDWIDTH (bandwidth) 40" in b.stdout
+    c = subprocess.run(base + ["-matrix", "14p43g", "-gapopen", "-20", "-gapextn", "-3"], cwd=G, capture_output=True, text=True)
+    assert "GAP_OPEN = -20" in c.stdout and "GAP_EXT = -3" in c.stdout
+    d = subprocess.run(base + ["-matrix", "14p43g", "-gapopen", "-20"], cwd=G, capture_output=True, text=True)
+    assert "GAP_OPEN = -33" in d.stdout                                       # both are required (ram_extend.c:292-293)
+
+
+def test_extend_alignment_struct_entry():
+    """Seam 1 with the reference's own struct layout: linked list, seqLib, scoringSystem (ram_extend.h:9-13)."""
+    import ctypes as C
+    import numpy as np
+    from oracle import pyoracle as po
+    from repeatafterme_amd.loader import _Core, _SeqLib
+    from repeatafterme_amd.scoring import _Scoring
+    from repeatafterme_amd.synth import synth_adversarial
+    from repeatafterme_amd.datamodel import new_master
+    L = _lib.lib()
+    L.ramx_get_matrix.restype = C.POINTER(_Scoring); L.ramx_get_matrix.argtypes = [C.c_char_p]
+    L.ramx_extend_alignment.restype = C.c_int
+    L.ramx_extend_alignment.argtypes = [C.c_int, C.POINTER(_Core), C.c_void_p, C.POINTER(_SeqLib), C.c_void_p, C.c_int,
+                                        C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_Scoring), C.c_void_p]
+    fs = synth_adversarial(33)
+    c = fs.cores
+    n = c.n
+    arr = (_Core * n)()
+    for i in range(n):
+        a = arr[i]
+        a.next = C.pointer(arr[i + 1]) if i + 1 < n else None
+        a.seqIdx = int(c.seq_idx[i]); a.leftSeqPos = int(c.left_pos[i]); a.rightSeqPos = int(c.right_pos[i])
+        a.leftExtendable = bytes([int(c.left_ext[i])]); a.rightExtendable = bytes([int(c.right_ext[i])])
+        a.lowerSeqBound = int(c.lower[i]); a.upperSeqBound = int(c.upper[i]); a.orient = bytes([int(c.orient[i])])
+    seq = np.ascontiguousarray(fs.sequence)
+    sl = _SeqLib(seq.ctypes.data_as(C.POINTER(C.c_int8)), None, None, None, len(seq), 0, 0, None)
+    sp = L.ramx_get_matrix(b"20p43g")
+    Lx, W = 90, 14
+    m = new_master(Lx)
+    L.ramx_set_runtime(0, 25, 1)
+    rr = L.ramx_extend_alignment(1, arr, None, C.byref(sl), m.ctypes.data, W, -90, 27, Lx, n, sp, None)
+    rl = L.ramx_extend_alignment(0, arr, None, C.byref(sl), m.ctypes.data, W, -90, 27, Lx, n, sp, None)
+    p = po.Params.named("20p43g", bandwidth=W, L=Lx, when_to_stop=25)
+    c2 = c.copy(); m2 = new_master(Lx)
+    o1 = po.oracle_extend(1, c2, fs.sequence, m2, p); o0 = po.oracle_extend(0, c2, fs.sequence, m2, p)
+    assert (rr, rl) == (o1.ret, o0.ret) and np.array_equal(m, m2)
+    assert [a.rightExtensionLen for a in arr] == c2.right_len.tolist()
+    assert [a.leftExtensionLen for a in arr] == c2.left_len.tolist()
+    assert [a.score for a in arr] == c2.score.tolist()

@@ -1,0 +1,68 @@
+"""BASELINE.json configs[2] size (N = 100,000 flanks x L = 10,000 bp, bandwidth 40): parity against the
+oracle on a column prefix of the FULL flank set, and size-independent properties of the full run."""
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+from repeatafterme_amd.datamodel import new_master
+from repeatafterme_amd.synth import synth_family
+
+from helpers import gpu_extend, to_extend_params
+
+pytestmark = pytest.mark.gpu
+
+N, L, W, K = 100_000, 10_000, 40, 1500
+
+
+@pytest.fixture(scope="module")
+def family():
+    return synth_family(N, L, W, K=K, seed=1)
+
+
+def test_full_width_prefix_bit_exact_vs_oracle(family):
+    """All 100,000 flanks, first 24 columns: int32-exact column sums drive the same consensus, lengths, scores."""
+    fs = family
+    p = po.Params.named("14p43g", bandwidth=W, L=24, when_to_stop=24)
+    c1, c2 = fs.cores.copy(), fs.cores.copy()
+    m1, m2 = new_master(24), new_master(24)
+    a = po.oracle_extend(1, c1, fs.sequence, m1, p, trace=True)
+    b = gpu_extend(1, c2, fs.sequence, m2, p)
+    assert a.ret == b.ret and a.rows_executed == b.rows_executed == 24
+    assert np.array_equal(m1, m2)
+    assert np.array_equal(c1.right_len, c2.right_len) and np.array_equal(c1.score, c2.score)
+    assert int(np.abs(a.col_sums).max()) < 2 ** 31 and b.overflow32 == 0
+
+
+def test_full_run_properties(family):
+    """Full 10,000-column run: (1) recovers the planted ancestor, (2) idempotent, (3) invariant under a
+    permutation of the flanks (integer sums are order independent), (4) the int32 guard holds."""
+    fs = family
+    p = po.Params.named("14p43g", bandwidth=W, L=L)           # default stopafter = 100
+    c = fs.cores.copy(); m = new_master(L)
+    r = gpu_extend(1, c, fs.sequence, m, p)
+    assert r.ret == K and r.rows_executed == K + 100 and r.overflow32 == 0
+    anc = np.random.default_rng(1).integers(0, 4, size=K, dtype=np.int8)   # first draw of synth_family(seed=1)
+    cons = m[L + 1: L + 1 + K]
+    assert (cons == anc).mean() > 0.995
+    assert (c.right_len > 0).mean() > 0.99 and abs(np.median(c.right_len) - K) < 0.05 * K
+    c2 = fs.cores.copy(); m2 = new_master(L)
+    r2 = gpu_extend(1, c2, fs.sequence, m2, p)
+    assert r2.ret == r.ret and np.array_equal(m, m2) and np.array_equal(c.score, c2.score)
+    perm = np.random.default_rng(5).permutation(N)
+    c3 = fs.cores.subset(perm); m3 = new_master(L)
+    r3 = gpu_extend(1, c3, fs.sequence, m3, p)
+    assert r3.ret == r.ret and np.array_equal(m, m3)
+    assert np.array_equal(c3.right_len, c.right_len[perm]) and np.array_equal(c3.score, c.score[perm])
+
+
+def test_forced_full_length_run_is_deterministic(family):
+    """stopafter = L forces all 10,000 columns (the bench workload); two runs agree on every output."""
+    fs = family
+    p = po.Params.named("14p43g", bandwidth=W, L=L, when_to_stop=L)
+    outs = []
+    for _ in range(2):
+        c = fs.cores.copy(); m = new_master(L)
+        r = gpu_extend(1, c, fs.sequence, m, p)
+        assert r.rows_executed == L and r.ret == K
+        outs.append((m.copy(), c.right_len.copy(), c.score.copy()))
+    assert all(np.array_equal(x, y) for x, y in zip(*outs))

@@ -1,0 +1,138 @@
+"""Parity tests proper: the HIP path, called through the C-ABI, against the oracle and the committed
+golden vectors.  Bit-exact: integer scores, identical consensus strings and extension lengths."""
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+from repeatafterme_amd.synth import synth_adversarial, synth_family
+
+from helpers import (assert_same_result, gpu_extend, load_api_vectors, oracle_extend, run_both_directions,
+                     to_extend_params)
+
+pytestmark = pytest.mark.gpu
+
+
+def test_gpu_reproduces_golden_vectors():
+    """tests/golden/api_vectors.npz: results of the compiled reference on 50 in-memory sets."""
+    for k, mat, seq, cores, p, exp in load_api_vectors():
+        c, m, rr, rl = run_both_directions(gpu_extend, cores, seq, p)
+        assert [rr.ret, rl.ret] == exp["ret"].tolist(), f"case {k} ({mat})"
+        assert np.array_equal(m, exp["master"]), f"case {k}"
+        assert np.array_equal(c.left_len, exp["left_len"]) and np.array_equal(c.right_len, exp["right_len"]), f"case {k}"
+        assert np.array_equal(c.score, exp["score"]), f"case {k}"
+
+
+@pytest.mark.parametrize("W", [0, 1, 3, 14, 40, 80])
+def test_gpu_adversarial_sets(W):
+    """Ragged hostile sets: truncated flanks, N runs, both strands, lower-case codes, tightened bounds,
+    mixed extendable flags, cores at array position 0 -- every matrix family."""
+    for seed in range(200, 216):
+        fs = synth_adversarial(seed, lowercase=(seed % 4 == 0))
+        for mat in ("14p43g", "18p43g", "20p43g", "25p43g", "repeatscout"):
+            p = po.Params.named(mat, bandwidth=W, L=120 if seed % 2 else 50, when_to_stop=30 if seed % 3 else 100)
+            a = run_both_directions(oracle_extend, fs.cores, fs.sequence, p)
+            b = run_both_directions(gpu_extend, fs.cores, fs.sequence, p)
+            assert_same_result(a[0], a[1], a[2:], b[0], b[1], b[2:], f"seed={seed} W={W} {mat}")
+            assert a[2].rows_executed == b[2].rows_executed and a[3].rows_executed == b[3].rows_executed
+            assert a[2].limit_warning == b[2].limit_warning and a[3].limit_warning == b[3].limit_warning
+
+
+def test_gpu_stop_rule_edges():
+    """WHEN_TO_STOP / L / MINIMPROVEMENT / CAPPENALTY corners: stopafter 0 and 1, L = 1, loop running out
+    exactly at L-1 (limit warning), negative minimprovement, zero cap."""
+    fs = synth_family(96, 80, 8, K=40, seed=11, both_sides=True, minus_frac=0.3)
+    for kw in (dict(when_to_stop=0), dict(when_to_stop=1), dict(L=1), dict(L=2, when_to_stop=1), dict(when_to_stop=40),
+               dict(minimprovement=-5), dict(minimprovement=0, when_to_stop=7), dict(cappenalty=0), dict(cappenalty=-100000),
+               dict(L=41, when_to_stop=1), dict(L=60, when_to_stop=20)):
+        args = dict(bandwidth=8, L=80, when_to_stop=100)
+        args.update(kw)
+        p = po.Params.named("20p43g", **args)
+        a = run_both_directions(oracle_extend, fs.cores, fs.sequence, p)
+        b = run_both_directions(gpu_extend, fs.cores, fs.sequence, p)
+        assert_same_result(a[0], a[1], a[2:], b[0], b[1], b[2:], str(kw))
+        assert (a[2].rows_executed, a[2].limit_warning, a[3].rows_executed, a[3].limit_warning) == \
+               (b[2].rows_executed, b[2].limit_warning, b[3].rows_executed, b[3].limit_warning), str(kw)
+
+
+def test_gpu_empty_and_degenerate_inputs():
+    from repeatafterme_amd.datamodel import CoreSet
+    # no cores at all; cores present but none extendable; a single flank; flank of length zero
+    seq = np.array([0, 1, 2, 3] * 20, np.int8)
+    p = po.Params.named("14p43g", bandwidth=5, L=30, when_to_stop=10)
+    sets = [
+        CoreSet(left_pos=[], right_pos=[], lower=[], upper=[], orient=[], left_ext=[], right_ext=[]),
+        CoreSet(left_pos=[10, 30], right_pos=[12, 33], lower=[0, 20], upper=[19, 79], orient=[0, 0], left_ext=[0, 0], right_ext=[0, 0]),
+        CoreSet(left_pos=[10], right_pos=[12], lower=[0], upper=[79], orient=[0], left_ext=[1], right_ext=[1]),
+        CoreSet(left_pos=[0, 79], right_pos=[79, 0], lower=[0, 0], upper=[79, 79], orient=[0, 1], left_ext=[1, 1], right_ext=[1, 1]),
+    ]
+    for i, c in enumerate(sets):
+        a = run_both_directions(oracle_extend, c, seq, p)
+        b = run_both_directions(gpu_extend, c, seq, p)
+        assert_same_result(a[0], a[1], a[2:], b[0], b[1], b[2:], f"degenerate {i}")
+        assert a[2].rows_executed == b[2].rows_executed
+
+
+def test_gpu_wide_band_generic_path():
+    """bandwidth 500 (util/davidExtendConsRAM.pl:248 uses it): no on-chip band limit in this design."""
+    fs = synth_family(70, 150, 500, K=100, seed=4, both_sides=False, minus_frac=0.3)
+    p = po.Params.named("25p43g", bandwidth=500, L=150, when_to_stop=30)
+    a = run_both_directions(oracle_extend, fs.cores, fs.sequence, p)
+    b = run_both_directions(gpu_extend, fs.cores, fs.sequence, p)
+    assert_same_result(a[0], a[1], a[2:], b[0], b[1], b[2:], "W=500")
+
+
+def test_gpu_config2_n1000_l2000_bit_exact():
+    """BASELINE.json configs[1]: synthetic N=1,000 x L=2,000, bandwidth 40, 14p43g -- full run vs oracle."""
+    fs = synth_family(1000, 2000, 40, K=1500, seed=1)
+    p = po.Params.named("14p43g", bandwidth=40, L=2000)
+    a = run_both_directions(oracle_extend, fs.cores, fs.sequence, p)
+    b = run_both_directions(gpu_extend, fs.cores, fs.sequence, p)
+    assert_same_result(a[0], a[1], a[2:], b[0], b[1], b[2:], "cfg2")
+    assert a[2].ret == 1500 and b[2].rows_executed == 1600
+    assert b[2].overflow32 == 0
+
+
+def test_gpu_both_sides_mixed_strands_20k():
+    fs = synth_family(20000, 500, 40, K=260, seed=2, both_sides=True, minus_frac=0.3, n_run_frac=0.05)
+    p = po.Params.named("14p43g", bandwidth=40, L=500)
+    a = run_both_directions(oracle_extend, fs.cores, fs.sequence, p)
+    b = run_both_directions(gpu_extend, fs.cores, fs.sequence, p)
+    assert_same_result(a[0], a[1], a[2:], b[0], b[1], b[2:], "20k")
+
+
+def test_gpu_band_state_bit_exact_per_cell():
+    """Seam 2: after r columns the DP row in HBM equals the oracle's row, cell by cell, both states
+    (what bnw_extend.c:1617-1648 asserts for the reference), plus high/pos."""
+    from repeatafterme_amd.device import Device, resolve_flanks
+    fs = synth_family(130, 60, 9, K=40, seed=21, both_sides=True, minus_frac=0.4, n_run_frac=0.2)
+    W, L = 9, 37
+    p = po.Params.named("18p43g", bandwidth=W, L=L, when_to_stop=1000)
+    for direction in (1, 0):
+        dev = Device(0)
+        dev.load_library(fs.sequence)
+        flanks, idx = resolve_flanks(direction, fs.cores, W, L)
+        dev.begin_direction(flanks, to_extend_params(p))
+        info = dev.run_direction()
+        cons, th, tp = dev.download()
+        assert info.rows_executed == L
+        # drive the oracle row function with the device's consensus and compare the final rows
+        B = 2 * W + 1
+        n_align = fs.cores.n
+        score = np.zeros((2, n_align, B, 2), np.int32)
+        for o in range(-W, W + 1):
+            score[1, :, o + W, :] = 0 if o == 0 else abs(o) * p.gapextn + p.gapopen
+        c = fs.cores
+        high = np.zeros(n_align, np.int64); pos = np.zeros(n_align, np.int64)
+        for row in range(L):
+            for n in idx:
+                best, bi = po.oracle_nw_row(direction, row, int(n), n_align, int(cons[row]), int(c.left_pos[n]), int(c.right_pos[n]),
+                                            int(c.orient[n]), score, int(c.lower[n]), int(c.upper[n]), fs.sequence,
+                                            p.matrix, p.gapopen, p.gapextn, W)
+                if best > high[n]:
+                    high[n], pos[n] = best, bi
+        for i in (0, 1, len(idx) // 2, len(idx) - 1):
+            cells, hi, po_ = dev.peek_state(i)
+            n = idx[i]
+            assert np.array_equal(cells, score[(L - 1) % 2, n]), f"dir {direction} flank {i}"
+            assert (hi, po_) == (high[n], pos[n])
+        dev.close()
