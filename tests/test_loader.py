@@ -193,6 +193,7 @@ def test_overlap_avoidance_vs_quadratic_restatement():
         devnull = os.open(os.devnull, os.O_WRONLY); saved = os.dup(1); os.dup2(devnull, 1)
         try:
             L.ramx_overlap_avoidance(arr, C.byref(sl))
+            C.CDLL(None).fflush(None)
         finally:
             os.dup2(saved, 1); os.close(devnull); os.close(saved)
         assert [int(c.lowerSeqBound) for c in arr] == lowers and [int(c.upperSeqBound) for c in arr] == uppers, trial
