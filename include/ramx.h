@@ -190,7 +190,8 @@ int ramx_dev_run_direction(ramx_dev *d, ramx_run_info *info);
  * trimmed per-flank high score / position (trimmed_sequence_high_score[_pos], ram_extend.c:902-903). */
 int ramx_dev_download(ramx_dev *d, int8_t *cons, int32_t cons_cap, int32_t *trim_high, int32_t *trim_pos);
 
-/* debug / test hook: current DP row state of one flank as [2W+1][2] int32 (sub,gap) + high,pos */
+/* debug / test hook: current DP row state of one flank as [2W+1][2] int32 + high,pos.  The device stores each
+ * cell transformed: (m, e) = (max(sub,gap), max(sub+gapopen,gap)+gapextn) -- see csrc/ramx_device.hip. */
 int ramx_dev_peek_state(ramx_dev *d, int32_t flank, int32_t *cells, int32_t *high, int32_t *pos);
 
 /* multi-GPU: flanks are sharded over ranks; each column's 4 candidate sums are all-reduced

@@ -124,7 +124,7 @@ __global__ void ramx_pack_kernel(const signed char *__restrict__ lib, unsigned l
 #pragma unroll
     for (int i = 0; i < 8; i++)
     {
-      const int t = 8 * k + i - W;
+      const int t = 8 * k + i - W - 8;   // one leading pad word: nibble index t'' = t + W + 8
       unsigned c = 8;
       if (t >= f.t_lo && t <= f.t_hi)
       {
@@ -148,6 +148,20 @@ __global__ void ramx_pack_kernel(const signed char *__restrict__ lib, unsigned l
 // ------------------------------------------------------------------------------------------
 // column kernel
 // ------------------------------------------------------------------------------------------
+//
+// State kept per band cell (two int32, as in the reference's score[..][..][2]) is stored TRANSFORMED:
+//     m  = max(sub, gap)                  -- all the next row's substitution term needs   (bnw_extend.c:950-956)
+//     e  = max(sub + go, gap) + ge        -- all the next row's deletion term needs       (:892-905), and, read
+//                                            from the current row's previous cell, the insertion term (:972-985)
+// (sub, gap) -> (m, e) loses nothing the recurrence ever reads, and saves three VALU ops per cell per row.
+//
+// Candidate rows (row r+1 for A,C,G,T; only their best cell is needed, ram_extend.c:1005-1062).  With
+// go <= 0 and ge <= 0 (every built-in scoring system) the insertion chain can never hold the row maximum:
+//   emit_k = max(sub_k + go, gap_k) <= cell_k,  ins_{k+1} = emit_k + ge <= cell_k, and for a masked cell
+//   emit = max(v + go, v) = v = cell; by induction  max_k cell_k = max_k [ inb_k ? max(sub_k, del_k) : v_k ].
+// So CHAIN = false evaluates the four candidates with NO serial chain: sub_k = m_k + M[a][base] and the shared
+// del_k = e_{k+1}.  CHAIN = true keeps the full recurrence for user-supplied positive penalties.
+
 __device__ __forceinline__ long long wave_sum_ll(long long v)
 {
 #pragma unroll
@@ -155,102 +169,348 @@ __device__ __forceinline__ long long wave_sum_ll(long long v)
   return v;
 }
 
-// One band step j of the skewed pair {row r cell j, candidate rows r+1 cell j-1}.
-//   INIT : row "r" is the boundary row (ram_extend.c:909-946), generated instead of computed
-//   VIRT : j == B, only the candidates' last cell is evaluated
-template <bool INIT, bool VIRT>
-__device__ __forceinline__ void band_step(const KArgs &a, const int4 *s_tab, int j, int besta,
-                                          int Psub, int Pgap, int EPn, unsigned bcode, bool inb, int vF,
-                                          int vC, int &eC, int &mPrev, int &bestF, int &jbest,
-                                          int (&eA)[4], int (&bestA)[4], int &outSub, int &outGap)
+// The DP rows are written once per column and read once by the next launch.  Plain (cacheable) accesses are the
+// measured choice: the 131 MB ping-pong working set of the N = 100,000 workload stays largely resident in the
+// 256 MB Infinity Cache between launches; non-temporal accesses (-DRAMX_NT_LDST) were 25 % slower
+// (32.5 vs 26.1 us per column, profiles/r01_notes.md).
+__device__ __forceinline__ int4 ld_stream(const int4 *p)
 {
-  const int go = a.go, ge = a.ge;
-  const int4 s = s_tab[bcode];
-  int eCnew;
-  int m = 0;
-  if (VIRT)
-  {
-    eCnew = NEG - ge;   // so that the candidates' deletion term is exactly NEG (no cell B)
-  }
-  else
+#ifndef RAMX_NT_LDST
+  return *p;
+#else
+  typedef int v4i __attribute__((ext_vector_type(4)));
+  const v4i v = __builtin_nontemporal_load(reinterpret_cast<const v4i *>(p));
+  return make_int4(v.x, v.y, v.z, v.w);
+#endif
+}
+__device__ __forceinline__ void st_stream(int4 *p, int4 v)
+{
+#ifndef RAMX_NT_LDST
+  *p = v;
+#else
+  typedef int v4i __attribute__((ext_vector_type(4)));
+  v4i x; x.x = v.x; x.y = v.y; x.z = v.z; x.w = v.w;
+  __builtin_nontemporal_store(x, reinterpret_cast<v4i *>(p));
+#endif
+}
+
+__device__ __forceinline__ int imax(int x, int y) { return x > y ? x : y; }
+__device__ __forceinline__ int imax3(int x, int y, int z) { return imax(imax(x, y), z); }
+__device__ __forceinline__ int imed3(int x, int lo, int hi)   // median of three = clamp(x, lo, hi) for lo <= hi
+{
+  int d;
+  asm("v_med3_i32 %0, %1, %2, %3" : "=v"(d) : "v"(x), "v"(lo), "v"(hi));
+  return d;
+}
+
+// Per-lane running values of the skewed pair {row r, candidate rows r+1}.
+struct LaneDP
+{
+  int eC;        // e of row r cell j-1: the insertion term of cell j, and the deletion term of candidate cell j-2
+  int mPrev;     // m of row r cell j-1: the substitution predecessor of candidate cell j-1
+  int bestF, jbest;
+  int eA[4];     // CHAIN only: e of the candidates' previous cell
+  int bestA[4];
+};
+
+// Uniform (scalar) per-step quantities.
+struct StepU
+{
+  int j;         // band cell of row r handled by this step (candidates handle cell j-1 of row r+1)
+  int vF;        // OOB fill of row r   cell j    (bnw_extend.c:990-1002)
+  int vC;        // OOB fill of row r+1 cell j-1, or the "no such cell" value at j == 0
+  bool first;    // j == 0: there is no candidate cell -1
+  int hi;        // CHAIN fast path: upper clamp of the candidates' gap state (INT_MAX; NEG - ge at step 0)
+};
+
+// LDS score table: row b (base class 0..8, row 9 = zeros for masked cells) holds
+// {M[A][b], M[C][b], M[G][b], M[T][b], M[besta][b], 0, 0, 0}; 32 B rows.
+#define TAB_ROWS 10
+#define TAB_STRIDE 8
+
+// Table values of one step, fetched from LDS ahead of use (the lookups depend only on the base stream and
+// the bounds, never on the DP chain, so they are issued one slot early to hide the LDS latency).
+struct StepT
+{
+  int sF;        // M[besta][base]: substitution score of row r cell j
+  int4 s;        // M[A..T][base] (zeros when the candidates' cell is masked)
+  bool inb;      // t' = j + r inside the flank
+  bool inbC;     // inb && j > 0
+};
+
+template <bool OOB>
+__device__ __forceinline__ StepT fetch_step(const int *s_tab, unsigned bc, bool inb, bool first)
+{
+  StepT t;
+  t.inb = OOB ? inb : true;
+  t.inbC = OOB ? (inb && !first) : true;
+#ifdef RAMX_DBG_NOLDS   // timing ablation only
+  t.sF = (int)bc - 3;
+  t.s = make_int4((int)bc, (int)bc - 1, (int)bc - 2, 3 - (int)bc);
+#else
+  t.sF = s_tab[bc * TAB_STRIDE + 4];
+  const unsigned bcC = (OOB && !t.inbC) ? 9u : bc;   // row 9 of the table is all zeros
+  t.s = *reinterpret_cast<const int4 *>(s_tab + bcC * TAB_STRIDE);
+#endif
+  return t;
+}
+
+// One band step.  FIN: compute row r cell j from the previous row (Pm = m of cell j, PeNext = e of cell j+1);
+// !FIN (virtual step j == B): only the candidates' last cell.  INIT: row "r" is the boundary row
+// (ram_extend.c:909-946).  OOB = false is the fast path taken by a wave whose 64 flanks all cover the whole
+// band of both rows: no bounds selects at all.
+template <bool INIT, bool FIN, bool OOB, bool CHAIN>
+__device__ __forceinline__ void band_step(const int go, const int ge, const int W, const StepU u, const StepT t,
+                                          const int Pm, const int PeNext, LaneDP &L, int &outM, int &outE)
+{
+  int eCn, m = 0;
+  if (FIN)
   {
     int sub, gap;
     if (INIT)
     {
-      const int o = j - a.W;
+      const int o = u.j - W;
       sub = (o == 0) ? 0 : (go + (o < 0 ? -o : o) * ge);
       gap = sub;
-      m = sub;
     }
     else
     {
-      const int sF = (besta & 2) ? ((besta & 1) ? s.w : s.z) : ((besta & 1) ? s.y : s.x);
-      const int pm = Psub > Pgap ? Psub : Pgap;
-      sub = pm + sF;                              // bnw_extend.c:950-956
-      const int del = EPn + ge;                   // :892-905
-      const int ins = eC + ge;                    // :972-985
-      gap = ins > del ? ins : del;                // :1007-1010
-      sub = inb ? sub : vF;                       // :990-1002
-      gap = inb ? gap : vF;
-      m = gap > sub ? gap : sub;                  // :1015-1018
-      if (m > bestF) { bestF = m; jbest = j; }    // :1020-1024 (strict >: lowest offset wins ties)
+      sub = Pm + t.sF;                             // bnw_extend.c:950-956
+      gap = imax(L.eC, PeNext);                    // ins (:972-985) vs del (:892-905), :1007-1010
+      if (OOB)
+      {
+        sub = t.inb ? sub : u.vF;                  // :990-1002
+        gap = t.inb ? gap : u.vF;
+      }
     }
-    outSub = sub;
-    outGap = gap;
-    const int so = sub + go;
-    eCnew = so > gap ? so : gap;
+    m = imax(sub, gap);                            // :1015-1018
+    if (!INIT)
+    {
+      const bool better = m > L.bestF;             // :1020-1024 strict >: lowest offset wins ties
+      L.bestF = imax(m, L.bestF);
+      L.jbest = better ? u.j : L.jbest;
+    }
+    eCn = imax(sub + go, gap) + ge;
+    outM = m;
+    outE = eCn;
   }
-  if (j > 0)
+  else
+    eCn = NEG;                                     // cell B does not exist: candidates' del is exactly NEG
+  // candidates: cell j-1 of row r+1 for all four bases, from S(r) just computed (never stored)
+  const int sv[4] = { t.s.x, t.s.y, t.s.z, t.s.w };
+  if (CHAIN)
   {
-    const int delC = eCnew + ge;
-    const int sv[4] = { s.x, s.y, s.z, s.w };
+    int mSel, lo, hi;
+    if (OOB)
+    {
+      mSel = t.inbC ? L.mPrev : u.vC;              // masked cell: sub = gap = vC
+      lo = t.inbC ? eCn : u.vC;                    // del of the candidates (shared by the four)
+      hi = t.inbC ? 2147483647 : u.vC;
+    }
+    else
+    {
+      mSel = L.mPrev;                              // at step 0 this is the very negative initial value
+      lo = eCn;
+      hi = u.hi;                                   // INT_MAX, or NEG - ge at step 0: median(NEG, lo, hi) = NEG - ge
+    }
 #pragma unroll
     for (int c = 0; c < 4; c++)
     {
-      int subA = mPrev + sv[c];
-      const int insA = eA[c] + ge;
-      int gapA = insA > delC ? insA : delC;
-      subA = inb ? subA : vC;
-      gapA = inb ? gapA : vC;
-      const int cA = gapA > subA ? gapA : subA;
-      bestA[c] = cA > bestA[c] ? cA : bestA[c];
-      const int so = subA + go;
-      eA[c] = so > gapA ? so : gapA;
+      const int subA = mSel + sv[c];
+      const int gapA = imed3(L.eA[c], lo, hi);     // in bounds: max(ins, del); masked: vC
+      L.bestA[c] = imax3(L.bestA[c], subA, gapA);
+      L.eA[c] = imax(subA + go, gapA) + ge;
     }
   }
-  mPrev = m;
-  eC = eCnew;
+  else
+  {
+    int mSel, lo;
+    if (OOB)
+    {
+      mSel = t.inbC ? L.mPrev : u.vC;
+      lo = t.inbC ? eCn : u.vC;
+    }
+    else
+    {
+      mSel = L.mPrev;
+      lo = u.first ? NEG : eCn;                    // there is no candidate cell -1 to take e[0] as its deletion
+    }
+#pragma unroll
+    for (int c = 0; c < 4; c++) L.bestA[c] = imax3(L.bestA[c], mSel + sv[c], lo);
+  }
+  L.mPrev = m;
+  L.eC = eCn;
 }
 
-template <bool INIT, int BLOCK>
+// The whole band of one flank (one lane) for column r: streams S(r-1) in, S(r) out.
+template <bool INIT, bool OOB, bool CHAIN>
+__device__ __forceinline__ void run_band(const KArgs &a, const int *s_tab, const int4 *Sin, int4 *Sout,
+                                         const unsigned *bp, const int jlo, const int jhi, LaneDP &D, int &high, int &pos,
+                                         int4 (&buf)[PF], int4 (&far)[PF], unsigned w0, unsigned w1, unsigned w2)
+{
+  const int W = a.W, B = 2 * W + 1, Q = W + 1, go = a.go, ge = a.ge, r = a.r;
+  // OOB fill values (bnw_extend.c:990-1002): uniform per (row, cell)
+  const int edgeF = (r < W) ? go + (r + 1) * ge : SENT;        // row r,   cells j < W
+  const int edgeC = (r + 1 < W) ? go + (r + 2) * ge : SENT;    // row r+1, cells j-1 < W
+  const int vFirst = NEG - ge - (go > 0 ? go : 0);             // CHAIN: leaves eA = NEG after the masked step 0
+  const int ph4 = 4 * ((r + 8) & 7);
+  const size_t wstride = (size_t)a.Np;
+  auto make_u = [&](int j) {
+    StepU u;
+    u.j = j;
+    u.first = (j == 0);
+    u.hi = u.first ? NEG - ge : 2147483647;
+    if (OOB)
+    {
+      u.vF = (j < W) ? edgeF : SENT;
+      u.vC = u.first ? vFirst : ((j - 1 < W) ? edgeC : SENT);
+    }
+    else { u.vF = 0; u.vC = 0; }
+    return u;
+  };
+  // table lookups of the two steps of slot q (bc0/bc1: base classes of steps 2q and 2q+1)
+  auto fetch_slot = [&](int q, unsigned bc0, unsigned bc1, StepT &t0, StepT &t1) {
+    const int j0 = 2 * q, j1 = 2 * q + 1;
+    t0 = fetch_step<OOB>(s_tab, bc0, (j0 >= jlo) && (j0 <= jhi), j0 == 0);
+    t1 = fetch_step<OOB>(s_tab, bc1, (j1 >= jlo) && (j1 <= jhi), false);
+  };
+  // One regular slot q = (m,e) of cells 2q and 2q+1 of row r; candidate cells 2q-1 and 2q of row r+1.
+  auto regular_slot = [&](int q, int4 cur, int4 nxt, const StepT &t0, const StepT &t1) {
+    int m0, e0, m1, e1;
+    band_step<INIT, true, OOB, CHAIN>(go, ge, W, make_u(2 * q), t0, cur.x, cur.w, D, m0, e0);
+    band_step<INIT, true, OOB, CHAIN>(go, ge, W, make_u(2 * q + 1), t1, cur.z, nxt.y, D, m1, e1);
+#if defined(RAMX_DBG_NOMEM) || defined(RAMX_DBG_NOSTORE)
+    if (m0 == 0x7fffffff) Sout[(size_t)q * 64] = make_int4(m0, e0, m1, e1);
+#else
+    st_stream(Sout + (size_t)q * 64, make_int4(m0, e0, m1, e1));
+#endif
+  };
+  auto final_slot = [&](int4 cur, const StepT &t0, const StepT &t1) {
+    int m0, e0, m1, e1;
+    // cell B-1 has no deletion predecessor (bnw_extend.c:892); then the virtual step j = B
+    band_step<INIT, true, OOB, CHAIN>(go, ge, W, make_u(2 * W), t0, cur.x, NEG, D, m0, e0);
+    band_step<INIT, false, OOB, CHAIN>(go, ge, W, make_u(B), t1, 0, 0, D, m1, e1);
+    if (!INIT)
+    {
+      high = cur.z; pos = cur.w;
+      if (D.bestF > high) { high = D.bestF; pos = r + D.jbest - W; }   // ram_extend.c:1140-1150
+    }
+    st_stream(Sout + (size_t)W * 64, make_int4(m0, e0, high, pos));
+  };
+  auto nib = [](unsigned A0, unsigned A1, int k) { return ((k < 8 ? A0 : A1) >> (4 * (k & 7))) & 15u; };
+
+  // ---- full groups: 8 slots = 16 steps of branch-free straight-line code -------------------
+  const int G = W >> 3;
+  int q0 = 0;
+  unsigned A0 = __builtin_amdgcn_alignbit(w1, w0, ph4);
+  unsigned A1 = __builtin_amdgcn_alignbit(w2, w1, ph4);
+  StepT t0, t1;
+  fetch_slot(0, nib(A0, A1, 0), nib(A0, A1, 1), t0, t1);
+  for (int g = 0; g < G; g++, q0 += 8)
+  {
+    const unsigned *bq = bp + (size_t)(2 * g + 3) * wstride;
+    const unsigned w3 = bq[0], w4 = bq[wstride];               // next group's words, consumed at the END of this group
+#pragma unroll
+    for (int i = 0; i < PF; i++)
+    {
+      const int q = q0 + i;
+      int4 cur = make_int4(0, 0, 0, 0), nxt = cur;
+      if (!INIT)
+      {
+        cur = buf[i];
+        nxt = buf[(i + 1) % PF];
+        buf[i] = far[i];
+        const int qn = q + 2 * PF;
+#ifdef RAMX_DBG_NOMEM   // timing ablation only
+        far[i] = make_int4(cur.x + 1, cur.y - 1, cur.z + 2, cur.w - 2);
+#else
+        far[i] = ld_stream(Sin + (size_t)(qn < Q ? qn : Q - 1) * 64);
+#endif
+      }
+      StepT n0, n1;                                            // lookups of the NEXT slot, issued before this one's math
+      if (i + 1 < PF) fetch_slot(q + 1, nib(A0, A1, 2 * i + 2), nib(A0, A1, 2 * i + 3), n0, n1);
+      else
+      {
+        A0 = __builtin_amdgcn_alignbit(w3, w2, ph4);
+        A1 = __builtin_amdgcn_alignbit(w4, w3, ph4);
+        fetch_slot(q + 1, nib(A0, A1, 0), nib(A0, A1, 1), n0, n1);
+      }
+      regular_slot(q, cur, nxt, t0, t1);
+      t0 = n0; t1 = n1;
+    }
+    w0 = w2; w1 = w3; w2 = w4;
+  }
+  // ---- tail group: remaining regular slots (W % 8 of them) and the final slot ---------------
+#pragma unroll
+  for (int i = 0; i < PF; i++)
+  {
+    const int q = q0 + i;
+    if (q <= W)
+    {
+      int4 cur = make_int4(0, 0, 0, 0), nxt = cur;
+      if (!INIT) { cur = buf[i]; nxt = buf[(i + 1) % PF]; }
+      if (q < W)
+      {
+        StepT n0, n1;
+        fetch_slot(q + 1, nib(A0, A1, (2 * i + 2) & 15), nib(A0, A1, (2 * i + 3) & 15), n0, n1);
+        regular_slot(q, cur, nxt, t0, t1);
+        t0 = n0; t1 = n1;
+      }
+      else
+        final_slot(cur, t0, t1);
+    }
+  }
+}
+
+template <bool INIT, bool CHAIN, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void ramx_column_kernel(const KArgs a)
 {
   constexpr int WPB = BLOCK / 64;
-  __shared__ int4 s_tab[RAMX_NCLASS];
+  __shared__ __attribute__((aligned(16))) int s_tab[TAB_ROWS * TAB_STRIDE];
   __shared__ long long s_red[WPB][4];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
 
-  if (threadIdx.x < RAMX_NCLASS)
-    s_tab[threadIdx.x] = make_int4(a.tab[threadIdx.x][0], a.tab[threadIdx.x][1], a.tab[threadIdx.x][2],
-                                   a.tab[threadIdx.x][3]);
+  // ---- loads that do not depend on the vote are issued first, so that the prologue below (a dependent
+  // round trip to the control block and the vote shards) overlaps with them: two rings of PF slots
+  // (`buf` = slots 0..7, `far` = 8..15; inside the band every load is issued 2*PF slots = 32 band steps ahead
+  // of its use, ~16 KB in flight per wave), the flank bounds and the first three base words.
+  const int W = a.W, B = 2 * W + 1, Q = W + 1, r = a.r;
+  const int tile = blockIdx.x * WPB + wave;
+  const bool live = tile < (a.Np >> 6);
+  const int n = (live ? tile : 0) * 64 + lane;
+  const int4 *Sin = a.S_in + (size_t)(live ? tile : 0) * Q * 64 + lane;
+  int4 *Sout = a.S_out + (size_t)(live ? tile : 0) * Q * 64 + lane;
+  // base stream: step j reads nibble t'' = j + r + 8 (the packed windows carry one leading pad word so that
+  // r = -1 stays non-negative); per group of 16 steps the nibbles sit at ph .. ph+15 of three words
+  const unsigned *bp = a.bases + (size_t)((r + 8) >> 3) * a.Np + n;
+  int4 buf[PF], far[PF];
+  if (!INIT)
+  {
+#pragma unroll
+    for (int i = 0; i < PF; i++) buf[i] = ld_stream(Sin + (size_t)(i < Q ? i : Q - 1) * 64);
+#pragma unroll
+    for (int i = 0; i < PF; i++) far[i] = ld_stream(Sin + (size_t)(i + PF < Q ? i + PF : Q - 1) * 64);
+  }
+  const int2 bd = a.bounds[n];
+  const unsigned w0 = bp[0], w1 = bp[(size_t)a.Np], w2 = bp[2 * (size_t)a.Np];
 
   // ---- vote for row r, stop rule (every wave, redundantly; block 0 publishes) -------------
   int besta = 0;
   bool new_max = false;
   if (!INIT)
   {
-    const RamxCtl c = *a.ctl_in;
-    if (c.stopped)           // uniform: the host runs ahead of the device-side stop decision
-    {
-      if (blockIdx.x == 0 && threadIdx.x == 0) *a.ctl_out = c;   // keep both flip-flop slots stopped
-      return;
-    }
     long long v[4] = { 0, 0, 0, 0 };
     if (lane < a.nshards_in)
     {
       const long long *p = a.sums_in + lane * 4;
       v[0] = p[0]; v[1] = p[1]; v[2] = p[2]; v[3] = p[3];
+    }
+    const RamxCtl c = *a.ctl_in;
+    if (c.stopped)           // uniform: the host runs ahead of the device-side stop decision
+    {
+      if (blockIdx.x == 0 && threadIdx.x == 0) *a.ctl_out = c;   // keep both flip-flop slots stopped
+      return;
     }
     long long curr = 0;      // ram_extend.c:973-974
     int ovf = c.overflow;
@@ -283,119 +543,31 @@ __global__ __launch_bounds__(BLOCK) void ramx_column_kernel(const KArgs a)
     o.max_ext = 0; o.max_row = -1; o.stopped = 0; o.rows_done = 0; o.overflow = 0; o.besta = 0; o.pad = 0;
     *a.ctl_out = o;
   }
+  if (threadIdx.x < TAB_ROWS * TAB_STRIDE)
+  {
+    const int row = threadIdx.x / TAB_STRIDE, col = threadIdx.x % TAB_STRIDE;
+    int v = 0;
+    if (row < RAMX_NCLASS) v = (col < 4) ? a.tab[row][col] : (col == 4 ? a.tab[row][besta] : 0);
+    s_tab[threadIdx.x] = v;
+  }
   if (blockIdx.x == 0)
     for (int i = threadIdx.x; i < NSHARD * 4; i += BLOCK) a.sums_zero[i] = 0;
   __syncthreads();
 
   // ---- the band: one lane = one flank -----------------------------------------------------
-  const int W = a.W, B = 2 * W + 1, Q = W + 1;
-  const int tile = blockIdx.x * WPB + wave;
   long long contrib[4] = { 0, 0, 0, 0 };
-  if (tile < (a.Np >> 6))
+  if (live)
   {
-    const int n = tile * 64 + lane;
-    const int2 bd = a.bounds[n];
-    const int jlo = bd.x - a.r, jhi = bd.y - a.r;     // cell j is in bounds iff jlo <= j <= jhi
-    const int4 *Sin = a.S_in + (size_t)tile * Q * 64 + lane;
-    int4 *Sout = a.S_out + (size_t)tile * Q * 64 + lane;
-
-    // OOB fill values (bnw_extend.c:990-1002): uniform per (row, cell)
-    const int edgeF = (a.r < W) ? a.go + (a.r + 1) * a.ge : SENT;       // row r,   cells j < W
-    const int edgeC = (a.r + 1 < W) ? a.go + (a.r + 2) * a.ge : SENT;   // row r+1, cells j < W
-
-    // base words: t' = j + r runs over [max(r,0), r + B]; keep two words of lookahead
-    const int tp0 = a.r < 0 ? 0 : a.r;
-    int kw = tp0 >> 3;
-    const unsigned *bp = a.bases + n;
-    unsigned w0 = bp[(size_t)kw * a.Np];
-    unsigned w1 = bp[(size_t)(kw + 1) * a.Np];
-    unsigned w2 = bp[(size_t)(kw + 2) * a.Np];
-
-    int4 buf[PF];
-    if (!INIT)
-    {
+    const int jlo = bd.x - r, jhi = bd.y - r;        // cell j (row r) / j-1 (row r+1) is in bounds iff jlo <= j <= jhi
+    LaneDP D;
+    D.eC = NEG; D.mPrev = NEG - 1000000; D.bestF = NEG; D.jbest = 0;
 #pragma unroll
-      for (int i = 0; i < PF; i++) buf[i] = Sin[(size_t)(i < Q ? i : Q - 1) * 64];
-    }
-
-    int eC = NEG - a.ge, mPrev = 0, bestF = NEG, jbest = 0;
-    int eA[4] = { NEG - a.ge, NEG - a.ge, NEG - a.ge, NEG - a.ge };
-    int bestA[4] = { NEG, NEG, NEG, NEG };
+    for (int c = 0; c < 4; c++) { D.eA[c] = NEG; D.bestA[c] = NEG; }
     int high = 0, pos = 0;
-    int lastSub = 0, lastGap = 0;
-
-    for (int q0 = 0; q0 < Q; q0 += PF)
-    {
-#pragma unroll
-      for (int i = 0; i < PF; i++)
-      {
-        const int q = q0 + i;
-        if (q < Q)
-        {
-          int4 cur = make_int4(0, 0, 0, 0), nxt = make_int4(0, 0, 0, 0);
-          if (!INIT)
-          {
-            cur = buf[i];
-            nxt = buf[(i + 1) % PF];
-            const int qn = q + PF;
-            buf[i] = Sin[(size_t)(qn < Q ? qn : Q - 1) * 64];
-          }
-          // ---- even cell j = 2q (always a real cell) ----
-          {
-            const int j = 2 * q;
-            int tp = j + a.r; tp = tp < 0 ? 0 : tp;
-            if ((tp >> 3) != kw) { kw++; w0 = w1; w1 = w2; w2 = bp[(size_t)(kw + 2) * a.Np]; }
-            const unsigned bc = (w0 >> (4 * (tp & 7))) & 15u;
-            const bool inb = (j >= jlo) && (j <= jhi);
-            const int vF = (j < W) ? edgeF : SENT;
-            const int vC = (j - 1 < W) ? edgeC : SENT;
-            int EPn;
-            if (q < W) { const int so = cur.z + a.go; EPn = so > cur.w ? so : cur.w; }
-            else EPn = NEG - a.ge;    // cell B-1 has no deletion predecessor (bnw_extend.c:892)
-            int oS, oG;
-            band_step<INIT, false>(a, s_tab, j, besta, cur.x, cur.y, EPn, bc, inb, vF, vC, eC, mPrev, bestF,
-                                   jbest, eA, bestA, oS, oG);
-            lastSub = oS; lastGap = oG;
-          }
-          if (q < W)
-          {
-            // ---- odd cell j = 2q+1 ----
-            const int j = 2 * q + 1;
-            int tp = j + a.r; tp = tp < 0 ? 0 : tp;
-            if ((tp >> 3) != kw) { kw++; w0 = w1; w1 = w2; w2 = bp[(size_t)(kw + 2) * a.Np]; }
-            const unsigned bc = (w0 >> (4 * (tp & 7))) & 15u;
-            const bool inb = (j >= jlo) && (j <= jhi);
-            const int vF = (j < W) ? edgeF : SENT;
-            const int vC = (j - 1 < W) ? edgeC : SENT;
-            const int so = nxt.x + a.go;
-            const int EPn = so > nxt.y ? so : nxt.y;
-            int oS, oG;
-            band_step<INIT, false>(a, s_tab, j, besta, cur.z, cur.w, EPn, bc, inb, vF, vC, eC, mPrev, bestF,
-                                   jbest, eA, bestA, oS, oG);
-            Sout[(size_t)q * 64] = make_int4(lastSub, lastGap, oS, oG);
-          }
-          else
-          {
-            // ---- q == W: slot holds cell B-1 and (high,pos); virtual step j = B for the candidates ----
-            const int j = B;
-            int tp = j + a.r; tp = tp < 0 ? 0 : tp;
-            if ((tp >> 3) != kw) { kw++; w0 = w1; w1 = w2; w2 = bp[(size_t)(kw + 2) * a.Np]; }
-            const unsigned bc = (w0 >> (4 * (tp & 7))) & 15u;
-            const bool inb = (j >= jlo) && (j <= jhi);
-            const int vC = (j - 1 < W) ? edgeC : SENT;
-            int oS, oG;
-            band_step<INIT, true>(a, s_tab, j, besta, 0, 0, 0, bc, inb, SENT, vC, eC, mPrev, bestF, jbest, eA,
-                                  bestA, oS, oG);
-            if (!INIT)
-            {
-              high = cur.z; pos = cur.w;
-              if (bestF > high) { high = bestF; pos = a.r + jbest - W; }   // ram_extend.c:1140-1150
-            }
-            Sout[(size_t)q * 64] = make_int4(lastSub, lastGap, high, pos);
-          }
-        }
-      }
-    }
+    // wave-uniform choice: do all 64 flanks cover every cell of both rows?  (steps 0..B)
+    const bool all_in = !INIT && __all((jlo <= 0) && (jhi >= B));
+    if (all_in) run_band<INIT, false, CHAIN>(a, s_tab, Sin, Sout, bp, jlo, jhi, D, high, pos, buf, far, w0, w1, w2);
+    else run_band<INIT, true, CHAIN>(a, s_tab, Sin, Sout, bp, jlo, jhi, D, high, pos, buf, far, w0, w1, w2);
     if (INIT || new_max) a.trim[n] = make_int2(high, pos);   // ram_extend.c:1203-1207 (913-914 at init)
     if (n < a.Nx)
     {
@@ -403,7 +575,7 @@ __global__ __launch_bounds__(BLOCK) void ramx_column_kernel(const KArgs a)
 #pragma unroll
       for (int c = 0; c < 4; c++)
       {
-        int b = bestA[c] < 0 ? 0 : bestA[c];                   // ram_extend.c:1042
+        const int b = D.bestA[c] < 0 ? 0 : D.bestA[c];         // ram_extend.c:1042
         contrib[c] = (b >= capv) ? b : capv;                   // :1052-1062
       }
     }
@@ -458,7 +630,7 @@ struct ramx_dev
   RamxCtl final_ctl;
   // multi-GPU
   ncclComm_t comm; int rank, nranks;
-  int block;
+  int force_chain;   // RAMX_FORCE_CHAIN=1: always run the full candidate recurrence (test hook)
 };
 
 extern "C" int ramx_device_count(void)
@@ -493,9 +665,8 @@ extern "C" int ramx_dev_create(int ordinal, ramx_dev **out)
   HIPCHK(hipEventCreate(&d->ev_begin));
   HIPCHK(hipEventCreate(&d->ev_end));
   for (int i = 0; i < MAX_SAMPLES; i++) { HIPCHK(hipEventCreate(&d->ev_s0[i])); HIPCHK(hipEventCreate(&d->ev_s1[i])); }
-  d->block = 256;
-  const char *eb = getenv("RAMX_BLOCK");
-  if (eb) { int b = atoi(eb); if (b == 64 || b == 128 || b == 256) d->block = b; }
+  const char *eb = getenv("RAMX_FORCE_CHAIN");
+  d->force_chain = (eb && atoi(eb) != 0) ? 1 : 0;
   *out = d;
   return RAMX_OK;
 }
@@ -554,8 +725,8 @@ extern "C" int ramx_dev_begin_direction(ramx_dev *d, const ramx_flank *flanks, i
   const int W = p->bandwidth, Q = W + 1;
   const int Nx = n_flanks;
   const int Np = ((Nx + 63) / 64) * 64 > 0 ? ((Nx + 63) / 64) * 64 : 64;
-  // t' = o + r + W runs over [0, L + 2W + 1]; +2 words of lookahead read by the kernel
-  const int KW = (p->L + 2 * W + 2) / 8 + 4;
+  // t'' = o + r + W + 8 runs over [7, L + 2W + 9]
+  const int KW = (p->L + 2 * W + 2) / 8 + 8;   // + pad word in front, + lookahead words read by the kernel
   d->Nx = Nx; d->Np = Np; d->KW = KW; d->p = *p;
   // class table: tab[class][cand] = matrix[cand][code(class)], reference index order [cons][seq]
   for (int c = 0; c < RAMX_NCLASS; c++)
@@ -594,12 +765,12 @@ template <bool INIT>
 static void launch_column(ramx_dev *d, const KArgs &a)
 {
   const int tiles = d->Np / 64;
-  switch (d->block)
-  {
-    case 64: hipLaunchKernelGGL((ramx_column_kernel<INIT, 64>), dim3(tiles), dim3(64), 0, d->stream, a); break;
-    case 128: hipLaunchKernelGGL((ramx_column_kernel<INIT, 128>), dim3((tiles + 1) / 2), dim3(128), 0, d->stream, a); break;
-    default: hipLaunchKernelGGL((ramx_column_kernel<INIT, 256>), dim3((tiles + 3) / 4), dim3(256), 0, d->stream, a); break;
-  }
+  const dim3 grid((tiles + 3) / 4), block(256);
+  // the chain-free candidate evaluation is exact iff neither gap penalty is positive (see the kernel header)
+  if (a.go <= 0 && a.ge <= 0 && !d->force_chain)
+    hipLaunchKernelGGL((ramx_column_kernel<INIT, false, 256>), grid, block, 0, d->stream, a);
+  else
+    hipLaunchKernelGGL((ramx_column_kernel<INIT, true, 256>), grid, block, 0, d->stream, a);
 }
 
 extern "C" int ramx_dev_run_direction(ramx_dev *d, ramx_run_info *info)

@@ -133,6 +133,40 @@ def test_gpu_band_state_bit_exact_per_cell():
         for i in (0, 1, len(idx) // 2, len(idx) - 1):
             cells, hi, po_ = dev.peek_state(i)
             n = idx[i]
-            assert np.array_equal(cells, score[(L - 1) % 2, n]), f"dir {direction} flank {i}"
+            sub, gap = score[(L - 1) % 2, n, :, 0].astype(np.int64), score[(L - 1) % 2, n, :, 1].astype(np.int64)
+            want = np.stack([np.maximum(sub, gap), np.maximum(sub + p.gapopen, gap) + p.gapextn], axis=1)   # stored as (m, e)
+            assert np.array_equal(cells, want), f"dir {direction} flank {i}"
             assert (hi, po_) == (high[n], pos[n])
         dev.close()
+
+
+def test_gpu_full_recurrence_path_and_positive_penalties(monkeypatch):
+    """The chain-free candidate evaluation is used only when gapopen <= 0 and gapextn <= 0; positive penalties
+    (possible through -gapopen/-gapext) and RAMX_FORCE_CHAIN=1 run the full recurrence.  Both must match."""
+    from repeatafterme_amd.device import Device, resolve_flanks
+    fs = synth_adversarial(77)
+    for go, ge in ((4, -3), (-10, 2), (3, 1), (0, 0), (-28, -5)):
+        p = po.Params.named("20p43g", bandwidth=9, L=60, when_to_stop=20, gapopen=go, gapextn=ge)
+        a = run_both_directions(oracle_extend, fs.cores, fs.sequence, p)
+        b = run_both_directions(gpu_extend, fs.cores, fs.sequence, p)
+        assert_same_result(a[0], a[1], a[2:], b[0], b[1], b[2:], f"go={go} ge={ge}")
+    # forced full recurrence with ordinary penalties, through the device API (the flag is read at device creation)
+    monkeypatch.setenv("RAMX_FORCE_CHAIN", "1")
+    p = po.Params.named("14p43g", bandwidth=14, L=100, when_to_stop=30)
+    for seed in (5, 6):
+        fs = synth_adversarial(seed)
+        c = fs.cores.copy()
+        from repeatafterme_amd.datamodel import new_master
+        m = new_master(p.L)
+        o = po.oracle_extend(1, c, fs.sequence, m, p)
+        dev = Device(0)
+        dev.load_library(fs.sequence)
+        flanks, idx = resolve_flanks(1, fs.cores, p.bandwidth, p.L)
+        dev.begin_direction(flanks, to_extend_params(p))
+        info = dev.run_direction()
+        cons, th, tp = dev.download()
+        dev.close()
+        assert info.ret == o.ret and info.rows_executed == o.rows_executed
+        assert np.array_equal(cons, m[p.L + 1: p.L + 1 + info.rows_executed])
+        ok = (th > 0) & (tp >= 0)
+        assert np.array_equal((tp[ok] + 1), c.right_len[idx[ok]]) and np.array_equal(th[ok], c.score[idx[ok]])
