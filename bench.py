@@ -96,8 +96,13 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(local_rank % torch.cuda.device_count())
+        backend = os.environ.get("RAMX_BENCH_BACKEND", "nccl")   # gloo only for the over-subscribed 1-GPU rehearsal
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank % torch.cuda.device_count()))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     W, L, N = args.bandwidth, args.L, args.flanks
     mat, go, ge = get_matrix("14p43g")
@@ -107,11 +112,13 @@ def main():
     fs = synth_family(N, L, W, K=1500, seed=1 + rank)   # each rank: its own shard of the family
     t_gen = time.time() - t0
 
-    dev = Device(local_rank)
+    ndev = max(_lib.lib().ramx_device_count(), 1)
+    dev = Device(local_rank % ndev)     # (% ndev only matters when ranks are over-subscribed on purpose in tests)
     if world > 1:
-        uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        on = "cuda" if dist.get_backend() == "nccl" else "cpu"
+        uid = torch.zeros(128, dtype=torch.uint8, device=on)
         if rank == 0:
-            uid = torch.from_numpy(dev.unique_id().copy()).cuda()
+            uid = torch.from_numpy(dev.unique_id().copy()).to(on)
         dist.broadcast(uid, 0)
         dev.comm_init(uid.cpu().numpy(), rank, world)
     t0 = time.time()
@@ -136,15 +143,21 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
     cols = sum(i.rows_executed for i in infos)
     total_flanks = N * world
     value = cols * total_flanks / dt
-    kavg_ms = float(np.mean([i.kernel_ms_avg for i in infos]))
-    loop_ms = float(np.mean([i.loop_ms for i in infos]))
+    # average launch duration of the dominant kernel, measured live with HIP events on libramx's own stream over
+    # the timed region (ev_begin .. ev_end bracket the column loop inside ramx_dev_run_direction) / launches.
+    # It includes the inter-launch gaps, so it can only under-state `achieved`; the event-bracketed samples of
+    # single launches are reported next to it.
+    launches = sum(i.rows_executed for i in infos)
+    loop_ms = float(sum(i.loop_ms for i in infos))
+    kavg_ms = loop_ms / max(launches, 1)
+    ksample_ms = float(np.mean([i.kernel_ms_avg for i in infos]))
     abytes = algorithmic_bytes_per_flank_column(W) * N          # per launch, per GPU
     achieved = abytes / (kavg_ms * 1e-3) / 1e9 if kavg_ms > 0 else 0.0
     traffic = None
@@ -166,9 +179,10 @@ def main():
         "cell_updates_per_sec": cols / dt * total_flanks * (2 * W + 1) * 4,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": "ramx_column_kernel<false,256>", "kernel_avg_us": kavg_ms * 1e3,
-                     "loop_avg_us_per_column": loop_ms * 1e3 / max(infos[0].rows_executed, 1),
-                     "algorithmic_bytes_per_launch": abytes, "samples": int(sum(i.kernel_samples for i in infos))},
+                     "kernel": "ramx_column_kernel<false,false,256>", "kernel_avg_us": kavg_ms * 1e3,
+                     "kernel_avg_us_event_bracketed_samples": ksample_ms * 1e3,
+                     "algorithmic_bytes_per_flank_column": algorithmic_bytes_per_flank_column(W),
+                     "algorithmic_bytes_per_launch": abytes, "launches_timed": launches},
         "setup": {"synth_s": t_gen, "upload_pack_s": t_upload},
     }
     if rank == 0 and world == 1 and not args.no_cpu:

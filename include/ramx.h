@@ -199,9 +199,12 @@ int ramx_dev_peek_state(ramx_dev *d, int32_t flank, int32_t *cells, int32_t *hig
  * (ramx_comm_unique_id) and handed to the other ranks by the launcher (e.g. torch.distributed). */
 int ramx_comm_unique_id(uint8_t id[128]);
 int ramx_dev_comm_init(ramx_dev *d, const uint8_t id[128], int rank, int nranks);
-/* test hook: replaces RCCL by a caller-supplied all-reduce so the sharded control flow can be
- * exercised without a GPU collective (cb must sum 4 int64 in place across ranks, blocking). */
+/* test hook: replaces RCCL by a caller-supplied all-reduce so the sharded control flow (fold kernel, reduced
+ * vote consumed by the next column, replicated stop rule) can be exercised where RCCL cannot run, e.g. two
+ * ranks sharing the single GPU of a test box.  cb must sum 4 int64 in place across ranks and block until
+ * done.  Slow by construction (one stream synchronisation per column); never used by bench.py. */
 typedef void (*ramx_allreduce_cb)(long long *vals4, void *user);
+int ramx_dev_set_allreduce_cb(ramx_dev *d, ramx_allreduce_cb cb, void *user);
 
 /* ------------------------------------------------------------------------------------------
  * Scoring systems (reference score_system.h:23-37)

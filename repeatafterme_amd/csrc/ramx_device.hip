@@ -630,6 +630,7 @@ struct ramx_dev
   RamxCtl final_ctl;
   // multi-GPU
   ncclComm_t comm; int rank, nranks;
+  ramx_allreduce_cb cb; void *cb_user;
   int force_chain;   // RAMX_FORCE_CHAIN=1: always run the full candidate recurrence (test hook)
 };
 
@@ -785,7 +786,7 @@ extern "C" int ramx_dev_run_direction(ramx_dev *d, ramx_run_info *info)
   a.Np = d->Np; a.Nx = d->Nx; a.W = p.bandwidth; a.go = p.gapopen; a.ge = p.gapextn; a.cap = p.cappenalty;
   a.minimp = p.minimprovement; a.when_to_stop = p.when_to_stop;
   memcpy(a.tab, d->tab, sizeof(a.tab));
-  const bool multi = d->comm != NULL && d->nranks > 1;
+  const bool multi = (d->comm != NULL && d->nranks > 1) || d->cb != NULL;
 
   auto slot = [&](int r) { return d->d_sums + (size_t)(((r % 3) + 3) % 3) * NSHARD * 4; };
   HIPCHK(hipMemsetAsync(d->d_sums, 0, 3 * NSHARD * 4 * sizeof(long long), d->stream));
@@ -805,8 +806,20 @@ extern "C" int ramx_dev_run_direction(ramx_dev *d, ramx_run_info *info)
     if (multi)
     {
       hipLaunchKernelGGL(ramx_fold_kernel, dim3(1), dim3(64), 0, d->stream, slot(r), d->d_g);
-      ncclResult_t nr = ncclAllReduce(d->d_g, d->d_g, 4, ncclInt64, ncclSum, d->comm, d->stream);
-      if (nr != ncclSuccess) { ramx_set_error("ncclAllReduce: %s", ncclGetErrorString(nr)); return RAMX_ERR_COMM; }
+      if (d->cb)
+      {
+        long long h4[4];
+        HIPCHK(hipMemcpyAsync(h4, d->d_g, sizeof(h4), hipMemcpyDeviceToHost, d->stream));
+        HIPCHK(hipStreamSynchronize(d->stream));
+        d->cb(h4, d->cb_user);
+        HIPCHK(hipMemcpyAsync(d->d_g, h4, sizeof(h4), hipMemcpyHostToDevice, d->stream));
+        HIPCHK(hipStreamSynchronize(d->stream));
+      }
+      else
+      {
+        ncclResult_t nr = ncclAllReduce(d->d_g, d->d_g, 4, ncclInt64, ncclSum, d->comm, d->stream);
+        if (nr != ncclSuccess) { ramx_set_error("ncclAllReduce: %s", ncclGetErrorString(nr)); return RAMX_ERR_COMM; }
+      }
       a.sums_in = d->d_g; a.nshards_in = 1;
     }
     else { a.sums_in = slot(r); a.nshards_in = NSHARD; }
@@ -902,6 +915,14 @@ extern "C" int ramx_dev_peek_state(ramx_dev *d, int32_t flank, int32_t *cells, i
     if (2 * q + 1 < B) { cells[4 * q + 2] = v.z; cells[4 * q + 3] = v.w; }
     else { if (high) *high = v.z; if (pos) *pos = v.w; }
   }
+  return RAMX_OK;
+}
+
+extern "C" int ramx_dev_set_allreduce_cb(ramx_dev *d, ramx_allreduce_cb cb, void *user)
+{
+  if (!d) { ramx_set_error("ramx_dev_set_allreduce_cb: bad argument"); return RAMX_ERR_ARG; }
+  d->cb = cb;
+  d->cb_user = user;
   return RAMX_OK;
 }
 

@@ -87,3 +87,12 @@ class Device:
     def comm_init(self, uid: np.ndarray, rank: int, nranks: int):
         uid = np.ascontiguousarray(uid, dtype=np.uint8)
         _lib.check(self._L.ramx_dev_comm_init(self._h, uid.ctypes.data, rank, nranks), "ramx_dev_comm_init")
+
+    def set_allreduce_callback(self, fn):
+        """Test hook (ramx_dev_set_allreduce_cb): fn(list of 4 ints) -> list of 4 ints summed over ranks."""
+        def _cb(ptr, _user):
+            vals = fn([ptr[i] for i in range(4)])
+            for i in range(4):
+                ptr[i] = int(vals[i])
+        self._cb = _lib.ALLREDUCE_CB(_cb)      # keep the trampoline alive
+        _lib.check(self._L.ramx_dev_set_allreduce_cb(self._h, self._cb, None), "ramx_dev_set_allreduce_cb")

@@ -1,0 +1,78 @@
+"""The sharded control flow of libramx on the GPU: two ranks (processes) share the test box's single GPU, each
+owning half of the flanks; the per-column 4 x int64 vote is all-reduced through the test hook (gloo) because
+RCCL refuses two ranks on one device.  Everything but the ncclAllReduce call itself is the production path:
+fold kernel, reduced vote read by the next column kernel, stop rule replicated on every rank."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import pyoracle as po
+    from repeatafterme_amd.datamodel import new_master
+    from repeatafterme_amd.device import Device
+    from repeatafterme_amd.sharded import extend_alignment_sharded, gpu_engine
+    from repeatafterme_amd.synth import synth_family
+    from helpers import to_extend_params
+
+    def allreduce4(v):
+        t = torch.tensor(v, dtype=torch.int64)
+        dist.all_reduce(t)
+        return t.tolist()
+
+    def all_gather(x):
+        sizes = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(sizes, torch.tensor([len(x)]))
+        m = int(max(s.item() for s in sizes))
+        buf = torch.zeros(m, dtype=torch.int32); buf[:len(x)] = torch.from_numpy(np.asarray(x, np.int32))
+        outs = [torch.zeros(m, dtype=torch.int32) for _ in range(world)]
+        dist.all_gather(outs, buf)
+        return np.concatenate([o[:int(s.item())].numpy() for o, s in zip(outs, sizes)])
+
+    fs = synth_family(333, 150, 20, K=100, seed=12, both_sides=True, minus_frac=0.3, n_run_frac=0.1)
+    p = po.Params.named("14p43g", bandwidth=20, L=150, when_to_stop=25)
+    dev = Device(0)
+    dev.set_allreduce_callback(allreduce4)
+    dev.load_library(fs.sequence)
+    c = fs.cores.copy(); m = new_master(p.L)
+    rets = []
+    for d in (1, 0):
+        rets.append(extend_alignment_sharded(d, c, fs.sequence, m, to_extend_params(p), rank, world, gpu_engine(dev), all_gather))
+    dev.close()
+    out[rank] = (rets, m.copy(), c.left_len.copy(), c.right_len.copy(), c.score.copy())
+    dist.destroy_process_group()
+
+
+def test_two_ranks_one_gpu_equal_single_process_oracle():
+    from oracle import pyoracle as po
+    from repeatafterme_amd.datamodel import new_master
+    from repeatafterme_amd.synth import synth_family
+    world = 2
+    out = mp.Manager().dict()
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    fs = synth_family(333, 150, 20, K=100, seed=12, both_sides=True, minus_frac=0.3, n_run_frac=0.1)
+    p = po.Params.named("14p43g", bandwidth=20, L=150, when_to_stop=25)
+    c = fs.cores.copy(); m = new_master(p.L)
+    r1 = po.oracle_extend(1, c, fs.sequence, m, p); r0 = po.oracle_extend(0, c, fs.sequence, m, p)
+    for rank in range(world):
+        rets, mm, ll, rl, sc = out[rank]
+        assert rets == [(r1.ret, r1.rows_executed), (r0.ret, r0.rows_executed)], rank
+        assert np.array_equal(mm, m) and np.array_equal(ll, c.left_len) and np.array_equal(rl, c.right_len)
+        assert np.array_equal(sc, c.score)
