@@ -599,17 +599,6 @@ __global__ __launch_bounds__(BLOCK) void ramx_column_kernel(const KArgs a)
   }
 }
 
-// multi-GPU: fold the local shards to 4 values so RCCL moves exactly 4 x int64 per column
-__global__ void ramx_fold_kernel(const long long *sums, long long *g)
-{
-  const int lane = threadIdx.x;
-  long long v[4] = { 0, 0, 0, 0 };
-  if (lane < NSHARD) { v[0] = sums[lane * 4]; v[1] = sums[lane * 4 + 1]; v[2] = sums[lane * 4 + 2]; v[3] = sums[lane * 4 + 3]; }
-#pragma unroll
-  for (int k = 0; k < 4; k++) v[k] = wave_sum_ll(v[k]);
-  if (lane == 0) { g[0] = v[0]; g[1] = v[1]; g[2] = v[2]; g[3] = v[3]; }
-}
-
 // ------------------------------------------------------------------------------------------
 // host side of seam 2
 // ------------------------------------------------------------------------------------------
@@ -620,7 +609,7 @@ struct ramx_dev
   signed char *d_lib; unsigned long long lib_len; unsigned long long lib_cap;
   // per direction
   ramx_flank *d_flanks; unsigned *d_bases; int2 *d_bounds; int4 *d_state[2]; int2 *d_trim;
-  long long *d_sums; long long *d_g; RamxCtl *d_ctl; signed char *d_cons;
+  long long *d_sums; RamxCtl *d_ctl; signed char *d_cons;
   size_t cap_flanks, cap_bases, cap_state, cap_cons;
   RamxCtl *h_ctl;   // pinned, [2 checkpoints][2 slots]
   hipEvent_t ev_chk[2], ev_begin, ev_end, ev_s0[MAX_SAMPLES], ev_s1[MAX_SAMPLES];
@@ -660,7 +649,6 @@ extern "C" int ramx_dev_create(int ordinal, ramx_dev **out)
   HIPCHK(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
   HIPCHK(hipHostMalloc((void **)&d->h_ctl, 4 * sizeof(RamxCtl), hipHostMallocDefault));
   HIPCHK(hipMalloc((void **)&d->d_sums, 3 * NSHARD * 4 * sizeof(long long)));
-  HIPCHK(hipMalloc((void **)&d->d_g, 4 * sizeof(long long)));
   HIPCHK(hipMalloc((void **)&d->d_ctl, 2 * sizeof(RamxCtl)));
   for (int i = 0; i < 2; i++) HIPCHK(hipEventCreate(&d->ev_chk[i]));
   HIPCHK(hipEventCreate(&d->ev_begin));
@@ -679,7 +667,7 @@ extern "C" void ramx_dev_destroy(ramx_dev *d)
   (void)hipStreamSynchronize(d->stream);
   if (d->comm) (void)ncclCommDestroy(d->comm);
   (void)hipFree(d->d_lib); (void)hipFree(d->d_flanks); (void)hipFree(d->d_bases); (void)hipFree(d->d_bounds);
-  (void)hipFree(d->d_state[0]); (void)hipFree(d->d_state[1]); (void)hipFree(d->d_trim); (void)hipFree(d->d_sums); (void)hipFree(d->d_g);
+  (void)hipFree(d->d_state[0]); if (d->d_state[1] != d->d_state[0]) (void)hipFree(d->d_state[1]); (void)hipFree(d->d_trim); (void)hipFree(d->d_sums);
   (void)hipFree(d->d_ctl); (void)hipFree(d->d_cons);
   (void)hipHostFree(d->h_ctl);
   for (int i = 0; i < 2; i++) (void)hipEventDestroy(d->ev_chk[i]);
@@ -745,8 +733,16 @@ extern "C" int ramx_dev_begin_direction(ramx_dev *d, const ramx_flank *flanks, i
   const size_t state_bytes = (size_t)Np * Q * sizeof(int4);
   if (state_bytes > d->cap_state || !d->d_state[0])
   {
-    for (int i = 0; i < 2; i++) { if (d->d_state[i]) HIPCHK(hipFree(d->d_state[i])); d->d_state[i] = NULL; }
-    for (int i = 0; i < 2; i++) HIPCHK(hipMalloc((void **)&d->d_state[i], state_bytes));
+    // The row is updated IN PLACE: a lane only ever touches its own 16-byte column of the tile, reads slot q+16
+    // before it writes slot q, and launches are serialised, so one buffer serves as S(r-1) and S(r).  Halving the
+    // footprint (65.6 MB at N = 100,000) keeps the whole row set inside the Infinity Cache.
+    const bool pingpong = getenv("RAMX_PINGPONG") != NULL;     // A/B switch kept for profiling
+    if (d->d_state[0]) HIPCHK(hipFree(d->d_state[0]));
+    if (d->d_state[1] && d->d_state[1] != d->d_state[0]) HIPCHK(hipFree(d->d_state[1]));
+    d->d_state[0] = d->d_state[1] = NULL;
+    HIPCHK(hipMalloc((void **)&d->d_state[0], state_bytes));
+    if (pingpong) HIPCHK(hipMalloc((void **)&d->d_state[1], state_bytes));
+    else d->d_state[1] = d->d_state[0];
     d->cap_state = state_bytes;
   }
   if ((rc = ensure(&d->d_cons, &d->cap_cons, (size_t)p->L + 16))) return rc;
@@ -805,24 +801,27 @@ extern "C" int ramx_dev_run_direction(ramx_dev *d, ramx_run_info *info)
   {
     if (multi)
     {
-      hipLaunchKernelGGL(ramx_fold_kernel, dim3(1), dim3(64), 0, d->stream, slot(r), d->d_g);
+      // the vote shards of row r (32 x 4 x int64 = 1 KB) are summed across ranks in place; the column kernel then
+      // folds them exactly as in the single-GPU case.  One collective per column, no extra kernel.
       if (d->cb)
       {
-        long long h4[4];
-        HIPCHK(hipMemcpyAsync(h4, d->d_g, sizeof(h4), hipMemcpyDeviceToHost, d->stream));
+        long long h[NSHARD * 4], h4[4] = { 0, 0, 0, 0 };
+        HIPCHK(hipMemcpyAsync(h, slot(r), sizeof(h), hipMemcpyDeviceToHost, d->stream));
         HIPCHK(hipStreamSynchronize(d->stream));
+        for (int i = 0; i < NSHARD * 4; i++) h4[i & 3] += h[i];
         d->cb(h4, d->cb_user);
-        HIPCHK(hipMemcpyAsync(d->d_g, h4, sizeof(h4), hipMemcpyHostToDevice, d->stream));
+        memset(h, 0, sizeof(h));
+        memcpy(h, h4, sizeof(h4));
+        HIPCHK(hipMemcpyAsync(slot(r), h, sizeof(h), hipMemcpyHostToDevice, d->stream));
         HIPCHK(hipStreamSynchronize(d->stream));
       }
       else
       {
-        ncclResult_t nr = ncclAllReduce(d->d_g, d->d_g, 4, ncclInt64, ncclSum, d->comm, d->stream);
+        ncclResult_t nr = ncclAllReduce(slot(r), slot(r), NSHARD * 4, ncclInt64, ncclSum, d->comm, d->stream);
         if (nr != ncclSuccess) { ramx_set_error("ncclAllReduce: %s", ncclGetErrorString(nr)); return RAMX_ERR_COMM; }
       }
-      a.sums_in = d->d_g; a.nshards_in = 1;
     }
-    else { a.sums_in = slot(r); a.nshards_in = NSHARD; }
+    a.sums_in = slot(r); a.nshards_in = NSHARD;
     a.r = r; a.S_in = d->d_state[(r + 1) & 1]; a.S_out = d->d_state[r & 1];
     a.ctl_in = d->d_ctl + ((r + 1) & 1); a.ctl_out = d->d_ctl + (r & 1);
     a.sums_out = slot(r + 1); a.sums_zero = slot(r + 2);
