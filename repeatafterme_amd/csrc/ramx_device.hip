@@ -600,6 +600,284 @@ __global__ __launch_bounds__(BLOCK) void ramx_column_kernel(const KArgs a)
 }
 
 // ------------------------------------------------------------------------------------------
+// persistent kernel: the whole direction in ONE launch, DP rows resident in registers
+// ------------------------------------------------------------------------------------------
+//
+// For W known at compile time and N <= (resident waves) x 64 the row of a flank (2 x (2W+1) int32) fits the
+// lane's registers, so the row never travels: HBM sees only the base words (~12 words per flank per column) and
+// the 32-byte vote.  All L columns run inside one cooperative launch; the dependent-launch boundary of the
+// streaming kernel becomes a device-wide barrier that is fused with the vote:
+//
+//   column c, every block:   4 x int64 atomicAdd of its capped candidate sums into shard (blockIdx % 32) of vote
+//                            set (c+1) % 3, every adding thread drains (vmcnt 0), block barrier, then ONE
+//                            arrival atomic on the shard's counter;
+//   column c+1, wave 0:      lanes 0..31 poll "their" shard's counter (relaxed agent-scope loads + s_sleep,
+//                            bounded) until it shows all of the shard's blocks, read the four sums with
+//                            agent-scope loads, shuffle-reduce, publish vote + score table through LDS.
+//   Set (c+2) % 3 is zeroed by block 0 during column c (everybody finished reading it before arriving for
+//   column c; nobody adds to it before block 0 itself has arrived for column c+1).
+//
+// Placement independent: only agent-scope atomics / atomic loads touch shared words, no assumption on which
+// XCD a block runs; co-residency is checked by hipLaunchCooperativeKernel and every spin is bounded (a timeout
+// raises `err` and every block leaves).  Multi-GPU runs keep the per-column launches (RCCL sits between them).
+
+struct PShard { long long sum[4]; unsigned cnt; unsigned pad[7]; };   // 64 B: one cache line per shard
+
+struct PArgs
+{
+  int4 *S;                      // row state in HBM: read at start (boundary row from K(-1)), written back at the end
+  const unsigned *bases;
+  const int2 *bounds;
+  int2 *trim;
+  const long long *sums0;       // vote shards of row 0, produced by K(-1)
+  PShard *vote;                 // [3][NSHARD]
+  RamxCtl *ctl_out;
+  signed char *cons_out;
+  unsigned *err;                // != 0: a bounded spin gave up
+  int Np, Nx, r0, L, go, ge, cap, minimp, when_to_stop, nblocks;
+  int tab[RAMX_NCLASS][4];
+};
+
+#define PRK_SPIN_LIMIT (1u << 22)
+
+// Row state of the persistent kernel: m[B] in registers; e is kept as the 16-bit difference d = e - m in LDS.
+// With go <= 0:  m + go + ge <= e <= m + ge  (e = max(sub+go, gap) + ge, m = max(sub, gap)), so d lies in
+// [go + ge, ge] and int16 is exact whenever go + ge >= -32768 (checked on the host).  Each lane owns one dword per
+// cell pair (layout [j/2][thread] dwords, halves by parity of j): conflict-free ds_read_i16 / ds_write_b16.
+template <int W, bool OOB>
+__device__ __forceinline__ void prk_band(const PArgs &a, const int *s_tab, short *sD, const int r,
+                                         const unsigned (&w)[(2 * W + 1 + 8) / 8 + 2], const int jlo, const int jhi,
+                                         int (&M)[2 * W + 1], LaneDP &D)
+{
+  constexpr int B = 2 * W + 1;
+  const int go = a.go, ge = a.ge;
+  const int edgeF = (r < W) ? go + (r + 1) * ge : SENT;
+  const int edgeC = (r + 1 < W) ? go + (r + 2) * ge : SENT;
+  const int ph4 = 4 * ((r + 8) & 7);
+  short *myD = sD + 2 * threadIdx.x;
+#pragma unroll
+  for (int j = 0; j <= B; j++)
+  {
+    // the row itself occupies B registers: keep the scheduler from hoisting every table lookup of the fully
+    // unrolled band to the top; lookups may run at most one 8-step group ahead
+    if ((j & 7) == 0) __builtin_amdgcn_sched_barrier(0);
+    const unsigned A = __builtin_amdgcn_alignbit(w[(j >> 3) + 1], w[j >> 3], ph4);
+    const unsigned bc = (A >> (4 * (j & 7))) & 15u;
+    StepU u;
+    u.j = j; u.first = (j == 0); u.hi = 2147483647;
+    u.vF = (j < W) ? edgeF : SENT;
+    u.vC = u.first ? NEG : ((j - 1 < W) ? edgeC : SENT);
+    const StepT t = fetch_step<OOB>(s_tab, bc, (j >= jlo) && (j <= jhi), j == 0);
+    if (j < B)
+    {
+      const int Pm = M[j];
+      int PeNext = NEG;
+      if (j + 1 < B) PeNext = M[j + 1] + (int)myD[((j + 1) >> 1) * 512 + ((j + 1) & 1)];   // previous row's e of cell j+1
+      int m, e;
+      band_step<false, true, OOB, false>(go, ge, W, u, t, Pm, PeNext, D, m, e);
+      M[j] = m;
+      myD[(j >> 1) * 512 + (j & 1)] = (short)(e - m);
+    }
+    else
+    {
+      int dm, de;
+      band_step<false, false, OOB, false>(go, ge, W, u, t, 0, 0, D, dm, de);
+    }
+  }
+}
+
+template <int W>
+__global__ __launch_bounds__(256, 2) void ramx_persistent_kernel(const PArgs a)
+{
+  constexpr int B = 2 * W + 1, Q = W + 1, NW = (B + 8) / 8 + 2;
+  __shared__ __attribute__((aligned(16))) int s_tab[TAB_ROWS * TAB_STRIDE];
+  __shared__ long long s_red[4][4];
+  __shared__ long long s_vote[4];
+  __shared__ int s_fail;
+  __shared__ short sD[((B + 1) / 2) * 512];            // d = e - m, [cell pair][thread][parity]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tile = blockIdx.x * 4 + wave;
+  const bool live = tile < (a.Np >> 6);
+  const int n = (live ? tile : 0) * 64 + lane;
+  int4 *S = a.S + (size_t)(live ? tile : 0) * Q * 64 + lane;
+  short *myD = sD + 2 * threadIdx.x;
+
+  // ---- row state -> registers (m) and LDS (e - m) -----------------------------------------
+  int M[B];
+  int high, pos, thigh = 0, tpos = 0;
+  {
+#pragma unroll
+    for (int q = 0; q < W; q++)
+    {
+      const int4 v = S[(size_t)q * 64];
+      M[2 * q] = v.x; M[2 * q + 1] = v.z;
+      myD[q * 512] = (short)(v.y - v.x); myD[q * 512 + 1] = (short)(v.w - v.z);
+    }
+    const int4 v = S[(size_t)W * 64];
+    M[B - 1] = v.x; myD[W * 512] = (short)(v.y - v.x); high = v.z; pos = v.w;
+  }
+  const int2 bd = a.bounds[n];
+  const int shard = blockIdx.x % NSHARD;
+  const int my_shard_blocks = (a.nblocks - lane + NSHARD - 1) / NSHARD;   // wave 0, lane < 32: blocks arriving on shard `lane`
+
+  long long max_ext = 0;
+  int max_row = -1, rows_done = 0, ovf = 0, stopped = 0, failed = 0;
+  if (threadIdx.x == 0) s_fail = 0;
+
+  for (int r = 0; r < a.L; r++)
+  {
+    // ---- base words of this column (independent of the vote: issued before the wait) -------
+    unsigned w[NW];
+    {
+      const unsigned *bp = a.bases + (size_t)((r + 8) >> 3) * a.Np + n;
+#pragma unroll
+      for (int k = 0; k < NW; k++) w[k] = bp[(size_t)k * a.Np];
+    }
+    // ---- vote of row r -----------------------------------------------------------------------
+    if (wave == 0)
+    {
+      long long v[4] = { 0, 0, 0, 0 };
+      if (r == 0)
+      {
+        if (lane < NSHARD) { const long long *p = a.sums0 + lane * 4; v[0] = p[0]; v[1] = p[1]; v[2] = p[2]; v[3] = p[3]; }
+      }
+      else
+      {
+        PShard *sh = a.vote + (size_t)(r % 3) * NSHARD + (lane < NSHARD ? lane : 0);
+        unsigned spins = 0;
+        bool done = lane >= NSHARD;
+        for (;;)
+        {
+          if (!done) done = __hip_atomic_load(&sh->cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)my_shard_blocks;
+          if (__all(done)) break;
+          if (++spins > PRK_SPIN_LIMIT || ((spins & 1023u) == 0 && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0))
+          {
+            failed = 1;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(2);
+        }
+        if (lane < NSHARD && !failed)
+        {
+#pragma unroll
+          for (int k = 0; k < 4; k++) v[k] = __hip_atomic_load(&sh->sum[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; k++) v[k] = wave_sum_ll(v[k]);
+      if (lane == 0)
+      {
+        s_vote[0] = v[0]; s_vote[1] = v[1]; s_vote[2] = v[2]; s_vote[3] = v[3];
+        s_fail = failed;
+        if (failed) __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    __syncthreads();
+    if (s_fail) { failed = 1; break; }
+    long long curr = 0;
+    int besta = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+    {
+      const long long vk = s_vote[k];
+      if (vk > 2147483647LL || vk < -2147483648LL) ovf = 1;
+      if (vk > curr) { curr = vk; besta = k; }
+    }
+    int dist = max_row - r;
+    dist = dist < 0 ? -dist : dist;
+    const bool new_max = curr >= max_ext + (long long)dist * a.minimp;
+    if (new_max) { max_row = r; max_ext = curr; }
+    int d2 = r - max_row;
+    d2 = d2 < 0 ? -d2 : d2;
+    stopped = d2 >= a.when_to_stop;
+    rows_done = r + 1;
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.cons_out[r] = (signed char)besta;
+    // block 0 clears the vote set of row r+2 (see the protocol above)
+    if (blockIdx.x == 0 && threadIdx.x < NSHARD)
+    {
+      PShard *z = a.vote + (size_t)((r + 2) % 3) * NSHARD + threadIdx.x;
+#pragma unroll
+      for (int k = 0; k < 4; k++) __hip_atomic_store(&z->sum[k], 0LL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&z->cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // score table (column 4 follows besta)
+    if (threadIdx.x < TAB_ROWS * TAB_STRIDE)
+    {
+      const int row = threadIdx.x / TAB_STRIDE, col = threadIdx.x % TAB_STRIDE;
+      int v = 0;
+      if (row < RAMX_NCLASS) v = (col < 4) ? a.tab[row][col] : (col == 4 ? a.tab[row][besta] : 0);
+      s_tab[threadIdx.x] = v;
+    }
+    __syncthreads();
+
+    // ---- the band, rows in registers ---------------------------------------------------------
+    long long contrib[4] = { 0, 0, 0, 0 };
+    if (live)
+    {
+      const int jlo = bd.x - r, jhi = bd.y - r;
+      LaneDP D;
+      D.eC = NEG; D.mPrev = NEG - 1000000; D.bestF = NEG; D.jbest = 0;
+#pragma unroll
+      for (int c = 0; c < 4; c++) { D.eA[c] = NEG; D.bestA[c] = NEG; }
+      const bool all_in = __all((jlo <= 0) && (jhi >= B));
+      if (all_in) prk_band<W, false>(a, s_tab, sD, r, w, jlo, jhi, M, D);
+      else prk_band<W, true>(a, s_tab, sD, r, w, jlo, jhi, M, D);
+      if (D.bestF > high) { high = D.bestF; pos = r + D.jbest - W; }   // ram_extend.c:1140-1150
+      if (new_max) { thigh = high; tpos = pos; }                        // :1203-1207
+      if (n < a.Nx)
+      {
+        const int capv = high + a.cap;
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+        {
+          const int b = D.bestA[c] < 0 ? 0 : D.bestA[c];
+          contrib[c] = (b >= capv) ? b : capv;
+        }
+      }
+    }
+    if (stopped || r == a.L - 1) break;     // the vote of row r+1 will not be consumed
+#pragma unroll
+    for (int c = 0; c < 4; c++) contrib[c] = wave_sum_ll(contrib[c]);
+    if (lane == 0)
+    {
+#pragma unroll
+      for (int c = 0; c < 4; c++) s_red[wave][c] = contrib[c];
+    }
+    __syncthreads();
+    if (threadIdx.x < 4)
+    {
+      const long long t = s_red[0][threadIdx.x] + s_red[1][threadIdx.x] + s_red[2][threadIdx.x] + s_red[3][threadIdx.x];
+      PShard *sh = a.vote + (size_t)((r + 1) % 3) * NSHARD + shard;
+      __hip_atomic_fetch_add(&sh->sum[threadIdx.x], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // every adding / zeroing thread drains before the arrival
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+      PShard *sh = a.vote + (size_t)((r + 1) % 3) * NSHARD + shard;
+      __hip_atomic_fetch_add(&sh->cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+
+  // ---- write back: rows (so that the device state can be inspected / resumed), trim, control ----
+  if (live)
+  {
+#pragma unroll
+    for (int q = 0; q < W; q++)
+      S[(size_t)q * 64] = make_int4(M[2 * q], M[2 * q] + (int)myD[q * 512], M[2 * q + 1], M[2 * q + 1] + (int)myD[q * 512 + 1]);
+    S[(size_t)W * 64] = make_int4(M[B - 1], M[B - 1] + (int)myD[W * 512], high, pos);
+    a.trim[n] = make_int2(thigh, tpos);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+  {
+    RamxCtl o;
+    o.max_ext = max_ext; o.max_row = max_row; o.stopped = stopped; o.rows_done = rows_done; o.overflow = ovf; o.besta = 0;
+    o.pad = failed;
+    *a.ctl_out = o;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // host side of seam 2
 // ------------------------------------------------------------------------------------------
 struct ramx_dev
@@ -610,6 +888,8 @@ struct ramx_dev
   // per direction
   ramx_flank *d_flanks; unsigned *d_bases; int2 *d_bounds; int4 *d_state[2]; int2 *d_trim;
   long long *d_sums; RamxCtl *d_ctl; signed char *d_cons;
+  PShard *d_vote; unsigned *d_err;   // persistent kernel: fused vote / barrier words
+  int no_persistent; int last_persistent;
   size_t cap_flanks, cap_bases, cap_state, cap_cons;
   RamxCtl *h_ctl;   // pinned, [2 checkpoints][2 slots]
   hipEvent_t ev_chk[2], ev_begin, ev_end, ev_s0[MAX_SAMPLES], ev_s1[MAX_SAMPLES];
@@ -650,6 +930,9 @@ extern "C" int ramx_dev_create(int ordinal, ramx_dev **out)
   HIPCHK(hipHostMalloc((void **)&d->h_ctl, 4 * sizeof(RamxCtl), hipHostMallocDefault));
   HIPCHK(hipMalloc((void **)&d->d_sums, 3 * NSHARD * 4 * sizeof(long long)));
   HIPCHK(hipMalloc((void **)&d->d_ctl, 2 * sizeof(RamxCtl)));
+  HIPCHK(hipMalloc((void **)&d->d_vote, 3 * NSHARD * sizeof(PShard)));
+  HIPCHK(hipMalloc((void **)&d->d_err, 64));
+  d->no_persistent = getenv("RAMX_NO_PERSISTENT") != NULL;
   for (int i = 0; i < 2; i++) HIPCHK(hipEventCreate(&d->ev_chk[i]));
   HIPCHK(hipEventCreate(&d->ev_begin));
   HIPCHK(hipEventCreate(&d->ev_end));
@@ -668,7 +951,7 @@ extern "C" void ramx_dev_destroy(ramx_dev *d)
   if (d->comm) (void)ncclCommDestroy(d->comm);
   (void)hipFree(d->d_lib); (void)hipFree(d->d_flanks); (void)hipFree(d->d_bases); (void)hipFree(d->d_bounds);
   (void)hipFree(d->d_state[0]); if (d->d_state[1] != d->d_state[0]) (void)hipFree(d->d_state[1]); (void)hipFree(d->d_trim); (void)hipFree(d->d_sums);
-  (void)hipFree(d->d_ctl); (void)hipFree(d->d_cons);
+  (void)hipFree(d->d_ctl); (void)hipFree(d->d_cons); (void)hipFree(d->d_vote); (void)hipFree(d->d_err);
   (void)hipHostFree(d->h_ctl);
   for (int i = 0; i < 2; i++) (void)hipEventDestroy(d->ev_chk[i]);
   (void)hipEventDestroy(d->ev_begin); (void)hipEventDestroy(d->ev_end);
@@ -770,6 +1053,56 @@ static void launch_column(ramx_dev *d, const KArgs &a)
     hipLaunchKernelGGL((ramx_column_kernel<INIT, true, 256>), grid, block, 0, d->stream, a);
 }
 
+// ---- persistent path --------------------------------------------------------------------------
+template <int W>
+static int prk_capacity_blocks(int *out)
+{
+  int per_cu = 0, dev = 0, cus = 0;
+  HIPCHK(hipGetDevice(&dev));
+  HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ramx_persistent_kernel<W>, 256, 0));
+  if (per_cu > 2) per_cu = 2;          // __launch_bounds__(256, 2); the API over-reports by one for SGPR-heavy kernels
+  *out = per_cu * cus;
+  return RAMX_OK;
+}
+
+template <int W>
+static int prk_launch(ramx_dev *d, PArgs &pa, int blocks)
+{
+  void *args[] = { (void *)&pa };
+  HIPCHK(hipLaunchCooperativeKernel((const void *)ramx_persistent_kernel<W>, dim3(blocks), dim3(256), args, 0, d->stream));
+  return RAMX_OK;
+}
+
+// which band widths have a register-resident instantiation
+static bool prk_has_width(int W) { return W == 14 || W == 20 || W == 40; }
+
+static int prk_run(ramx_dev *d, const KArgs &a, int L, bool *used)
+{
+  *used = false;
+  const int W = a.W;
+  if (d->no_persistent || d->force_chain || a.go > 0 || a.ge > 0 || a.go + a.ge < -32768 || !prk_has_width(W) || L <= 0) return RAMX_OK;
+  if ((d->comm != NULL && d->nranks > 1) || d->cb != NULL) return RAMX_OK;
+  const int blocks = (d->Np / 64 + 3) / 4;
+  int cap = 0, rc;
+  rc = (W == 14) ? prk_capacity_blocks<14>(&cap) : (W == 20) ? prk_capacity_blocks<20>(&cap) : prk_capacity_blocks<40>(&cap);
+  if (rc != RAMX_OK) return rc;
+  if (blocks > cap) return RAMX_OK;     // not co-resident: keep the streaming kernel
+  PArgs pa;
+  memset(&pa, 0, sizeof(pa));
+  pa.S = d->d_state[0]; pa.bases = d->d_bases; pa.bounds = d->d_bounds; pa.trim = d->d_trim;
+  pa.sums0 = d->d_sums; pa.vote = d->d_vote; pa.ctl_out = d->d_ctl; pa.cons_out = d->d_cons; pa.err = d->d_err;
+  pa.Np = d->Np; pa.Nx = d->Nx; pa.r0 = 0; pa.L = L; pa.go = a.go; pa.ge = a.ge; pa.cap = a.cap; pa.minimp = a.minimp;
+  pa.when_to_stop = a.when_to_stop; pa.nblocks = blocks;
+  memcpy(pa.tab, a.tab, sizeof(pa.tab));
+  HIPCHK(hipMemsetAsync(d->d_vote, 0, 3 * NSHARD * sizeof(PShard), d->stream));
+  HIPCHK(hipMemsetAsync(d->d_err, 0, 64, d->stream));
+  rc = (W == 14) ? prk_launch<14>(d, pa, blocks) : (W == 20) ? prk_launch<20>(d, pa, blocks) : prk_launch<40>(d, pa, blocks);
+  if (rc != RAMX_OK) return rc;
+  *used = true;
+  return RAMX_OK;
+}
+
 extern "C" int ramx_dev_run_direction(ramx_dev *d, ramx_run_info *info)
 {
   if (!d || !d->ready) { ramx_set_error("ramx_dev_run_direction: begin_direction has not been called"); return RAMX_ERR_STATE; }
@@ -793,11 +1126,19 @@ extern "C" int ramx_dev_run_direction(ramx_dev *d, ramx_run_info *info)
   launch_column<true>(d, a);
   HIPCHK(hipGetLastError());
   int launches = 0, nsamp = 0, pending = -1, chk = 0;
+  bool persistent = false;
+  {
+    // the in-place row buffer holds S(-1) after K(-1); d_ctl[1] holds the initial control block, the persistent
+    // kernel writes its final one to d_ctl[0]
+    if (d->d_state[0] != d->d_state[1]) { ramx_set_error("persistent path needs the in-place row buffer"); }
+    else { int prc = prk_run(d, a, L, &persistent); if (prc != RAMX_OK) return prc; }
+  }
+  d->last_persistent = persistent ? 1 : 0;
   const int CHUNK = 64;
   const int stride = L > MAX_SAMPLES * 4 ? L / MAX_SAMPLES : 4;
   bool stopped = false;
   memset(d->h_ctl, 0, 4 * sizeof(RamxCtl));
-  for (int r = 0; r < L && !stopped; r++)
+  for (int r = 0; r < L && !stopped && !persistent; r++)
   {
     if (multi)
     {
@@ -851,6 +1192,11 @@ extern "C" int ramx_dev_run_direction(ramx_dev *d, ramx_run_info *info)
   HIPCHK(hipMemcpy(h, d->d_ctl, sizeof(h), hipMemcpyDeviceToHost));
   const RamxCtl &f = (L == 0) ? h[1] : ((h[0].rows_done > h[1].rows_done) ? h[0] : h[1]);
   d->final_ctl = f;
+  if (persistent)
+  {
+    launches = 1;
+    if (f.pad != 0) { ramx_set_error("persistent kernel: device-wide barrier timed out (bounded spin gave up)"); return RAMX_ERR_STATE; }
+  }
   if (info)
   {
     info->ret = f.max_row + 1;
