@@ -133,6 +133,7 @@ typedef struct ramx_run_info
   double  kernel_ms_avg;    /* mean duration of sampled single column-kernel launches (HIP events) */
   int32_t kernel_samples;
   double  prep_ms;          /* host flatten + H2D + pack kernel (wall clock) */
+  int32_t persistent;       /* 1: the whole loop ran as ONE persistent launch (rows resident on chip) */
 } ramx_run_info;
 
 int ramx_extend_flat(int direction, ramx_flat_cores *cores, const int8_t *sequence, uint64_t seq_len,

@@ -889,7 +889,7 @@ struct ramx_dev
   ramx_flank *d_flanks; unsigned *d_bases; int2 *d_bounds; int4 *d_state[2]; int2 *d_trim;
   long long *d_sums; RamxCtl *d_ctl; signed char *d_cons;
   PShard *d_vote; unsigned *d_err;   // persistent kernel: fused vote / barrier words
-  int no_persistent; int last_persistent;
+  int last_persistent;
   size_t cap_flanks, cap_bases, cap_state, cap_cons;
   RamxCtl *h_ctl;   // pinned, [2 checkpoints][2 slots]
   hipEvent_t ev_chk[2], ev_begin, ev_end, ev_s0[MAX_SAMPLES], ev_s1[MAX_SAMPLES];
@@ -932,7 +932,7 @@ extern "C" int ramx_dev_create(int ordinal, ramx_dev **out)
   HIPCHK(hipMalloc((void **)&d->d_ctl, 2 * sizeof(RamxCtl)));
   HIPCHK(hipMalloc((void **)&d->d_vote, 3 * NSHARD * sizeof(PShard)));
   HIPCHK(hipMalloc((void **)&d->d_err, 64));
-  d->no_persistent = getenv("RAMX_NO_PERSISTENT") != NULL;
+
   for (int i = 0; i < 2; i++) HIPCHK(hipEventCreate(&d->ev_chk[i]));
   HIPCHK(hipEventCreate(&d->ev_begin));
   HIPCHK(hipEventCreate(&d->ev_end));
@@ -1081,7 +1081,7 @@ static int prk_run(ramx_dev *d, const KArgs &a, int L, bool *used)
 {
   *used = false;
   const int W = a.W;
-  if (d->no_persistent || d->force_chain || a.go > 0 || a.ge > 0 || a.go + a.ge < -32768 || !prk_has_width(W) || L <= 0) return RAMX_OK;
+  if (getenv("RAMX_NO_PERSISTENT") != NULL || d->force_chain || a.go > 0 || a.ge > 0 || a.go + a.ge < -32768 || !prk_has_width(W) || L <= 0) return RAMX_OK;
   if ((d->comm != NULL && d->nranks > 1) || d->cb != NULL) return RAMX_OK;
   const int blocks = (d->Np / 64 + 3) / 4;
   int cap = 0, rc;
@@ -1216,6 +1216,7 @@ extern "C" int ramx_dev_run_direction(ramx_dev *d, ramx_run_info *info)
     }
     info->kernel_ms_avg = cnt ? acc / cnt : 0.0;
     info->kernel_samples = cnt;
+    info->persistent = persistent ? 1 : 0;
   }
   return RAMX_OK;
 }

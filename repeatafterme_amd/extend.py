@@ -28,6 +28,7 @@ class RunInfo:
     kernel_ms_avg: float
     kernel_samples: int
     prep_ms: float
+    persistent: int = 0
 
 
 def _params(p: ExtendParams):

@@ -1,0 +1,101 @@
+"""The persistent register-resident kernel (one launch per direction, rows on chip, vote fused with a
+device-wide barrier) against the streaming per-column kernel and the oracle.  Band widths 14, 20 and 40 have a
+persistent instantiation; everything else, positive gap penalties, flank sets too large to be co-resident and
+multi-rank runs use the streaming kernel."""
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+from repeatafterme_amd.datamodel import CoreSet, new_master
+from repeatafterme_amd.synth import synth_adversarial, synth_family
+
+from helpers import assert_same_result, gpu_extend, oracle_extend, run_both_directions, to_extend_params
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_device(fs, p, direction, monkeypatch, persistent):
+    from repeatafterme_amd.device import Device, resolve_flanks
+    if persistent:
+        monkeypatch.delenv("RAMX_NO_PERSISTENT", raising=False)
+    else:
+        monkeypatch.setenv("RAMX_NO_PERSISTENT", "1")
+    dev = Device(0)
+    dev.load_library(fs.sequence)
+    flanks, idx = resolve_flanks(direction, fs.cores, p.bandwidth, p.L)
+    dev.begin_direction(flanks, to_extend_params(p))
+    info = dev.run_direction()
+    cons, th, tp = dev.download()
+    state = [dev.peek_state(i) for i in (0, max(len(idx) - 1, 0))] if len(idx) else []
+    dev.close()
+    return info, cons, th, tp, state
+
+
+@pytest.mark.parametrize("W", [14, 20, 40])
+def test_persistent_equals_streaming_and_oracle(W, monkeypatch):
+    for seed in (300, 301, 302, 303):
+        fs = synth_adversarial(seed, lowercase=(seed % 2 == 0))
+        p = po.Params.named("14p43g" if seed % 2 else "repeatscout", bandwidth=W, L=110, when_to_stop=25)
+        for direction in (1, 0):
+            a = _run_device(fs, p, direction, monkeypatch, True)
+            b = _run_device(fs, p, direction, monkeypatch, False)
+            assert a[0].persistent == 1 and b[0].persistent == 0
+            assert (a[0].ret, a[0].rows_executed, a[0].limit_warning) == (b[0].ret, b[0].rows_executed, b[0].limit_warning)
+            assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
+            for (ca, ha, pa), (cb, hb, pb) in zip(a[4], b[4]):      # final DP rows, cell by cell
+                assert np.array_equal(ca, cb) and (ha, pa) == (hb, pb)
+        x = run_both_directions(oracle_extend, fs.cores, fs.sequence, p)
+        y = run_both_directions(gpu_extend, fs.cores, fs.sequence, p)
+        assert_same_result(x[0], x[1], x[2:], y[0], y[1], y[2:], f"seed={seed} W={W}")
+
+
+def test_persistent_stop_rule_and_degenerate_inputs():
+    fs = synth_family(200, 90, 14, K=50, seed=17, both_sides=True, minus_frac=0.3)
+    for kw in (dict(when_to_stop=0), dict(when_to_stop=1), dict(L=1), dict(L=2, when_to_stop=1), dict(minimprovement=-3),
+               dict(cappenalty=0), dict(L=51, when_to_stop=1), dict(L=70, when_to_stop=20), dict(when_to_stop=1000)):
+        args = dict(bandwidth=14, L=90, when_to_stop=100)
+        args.update(kw)
+        p = po.Params.named("20p43g", **args)
+        a = run_both_directions(oracle_extend, fs.cores, fs.sequence, p)
+        b = run_both_directions(gpu_extend, fs.cores, fs.sequence, p)
+        assert_same_result(a[0], a[1], a[2:], b[0], b[1], b[2:], str(kw))
+        assert b[2].persistent == 1
+        assert (a[2].rows_executed, a[2].limit_warning, a[3].rows_executed, a[3].limit_warning) == \
+               (b[2].rows_executed, b[2].limit_warning, b[3].rows_executed, b[3].limit_warning), str(kw)
+    seq = np.array([0, 1, 2, 3] * 40, np.int8)
+    p = po.Params.named("14p43g", bandwidth=14, L=40, when_to_stop=10)
+    for c in (CoreSet(left_pos=[], right_pos=[], lower=[], upper=[], orient=[], left_ext=[], right_ext=[]),
+              CoreSet(left_pos=[10, 30], right_pos=[12, 33], lower=[0, 20], upper=[19, 159], orient=[0, 0], left_ext=[0, 0], right_ext=[0, 0]),
+              CoreSet(left_pos=[50], right_pos=[52], lower=[0], upper=[159], orient=[0], left_ext=[1], right_ext=[1])):
+        a = run_both_directions(oracle_extend, c, seq, p)
+        b = run_both_directions(gpu_extend, c, seq, p)
+        assert_same_result(a[0], a[1], a[2:], b[0], b[1], b[2:], "degenerate")
+        assert a[2].rows_executed == b[2].rows_executed and b[2].persistent == 1
+
+
+def test_mixed_fast_and_masked_waves_uneven_load():
+    """Waves on the in-bounds fast path and ragged waves on the masked path meet at the same barrier."""
+    a = synth_family(2000, 160, 40, K=120, seed=31, both_sides=True)
+    b = synth_adversarial(41, n_windows=40, L=160, W=40, K=100)
+    off = len(a.sequence)
+    seq = np.concatenate((a.sequence, b.sequence))
+    cores = CoreSet(**{k: np.concatenate((getattr(a.cores, k), getattr(b.cores, k) + (off if k in ("left_pos", "right_pos", "lower", "upper") else 0)))
+                       for k in ("left_pos", "right_pos", "lower", "upper", "orient", "left_ext", "right_ext")})
+    p = po.Params.named("14p43g", bandwidth=40, L=160, when_to_stop=40)
+    x = run_both_directions(oracle_extend, cores, seq, p)
+    y = run_both_directions(gpu_extend, cores, seq, p)
+    assert_same_result(x[0], x[1], x[2:], y[0], y[1], y[2:], "mixed")
+    assert y[2].persistent == 1
+
+
+def test_too_many_flanks_for_residency_fall_back_to_streaming():
+    """More flanks than resident lanes (2 blocks x 256 CUs x 256 lanes = 131,072): streaming kernel, same results."""
+    n = 131072 + 6400
+    fs = synth_family(n, 12, 40, K=12, seed=9)
+    p = po.Params.named("14p43g", bandwidth=40, L=12, when_to_stop=12)
+    c1, c2 = fs.cores.copy(), fs.cores.copy()
+    m1, m2 = new_master(12), new_master(12)
+    a = po.oracle_extend(1, c1, fs.sequence, m1, p)
+    b = gpu_extend(1, c2, fs.sequence, m2, p)
+    assert b.persistent == 0
+    assert a.ret == b.ret and np.array_equal(m1, m2) and np.array_equal(c1.right_len, c2.right_len) and np.array_equal(c1.score, c2.score)

@@ -8,7 +8,7 @@ for v in "" "$1=1"; do
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1])
 r = d['roofline']
-print('[$v] N', $n, 'us/col', round(r['kernel_avg_us'],2))
+print('[$v] N', $n, 'us/col', round(r['us_per_column'],2))
 "
   done
 done; done

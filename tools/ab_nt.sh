@@ -9,7 +9,7 @@ for v in "" "-DRAMX_PLAIN_LDST"; do
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1])
 r = d['roofline']
-print('variant [$v] N', $n, 'us/col', round(r['kernel_avg_us'],2))
+print('variant [$v] N', $n, 'us/col', round(r['us_per_column'],2))
 "
   done; done
 done

@@ -20,4 +20,4 @@ for set in \
   rocprofv3 --pmc $set --output-format csv -d $OUT/pass$i -- python3 bench.py $ARGS > $OUT/pass$i.log 2>&1 || echo "pass $i failed"
   echo "pass $i done: $set"
 done
-python3 tools/pmc_summary.py $OUT $TAG
+python3 tools/pmc_summary.py $OUT $TAG ${3:-256}

@@ -5,7 +5,7 @@ for blk in 64 128 256; do
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1])
 r = d['roofline']
-print('block', $blk, 'N', $n, 'us/col', round(r['kernel_avg_us'],2), 'GB/s', round($n*1312.25/r['kernel_avg_us']/1e3))
+print('block', $blk, 'N', $n, 'us/col', round(r['us_per_column'],2), 'GB/s', round($n*1312.25/r['us_per_column']/1e3))
 "
   done
 done

@@ -5,7 +5,7 @@ for n in 1000 100000; do
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1])
 r = d['roofline']
-print('N', $n, 'W', $w, 'us/col', round(r['kernel_avg_us'],2), 'GB/s', round(r['achieved']))
+print('N', $n, 'W', $w, 'us/col', round(r['us_per_column'],2), 'GB/s', round(r['achieved']))
 "
   done
 done
