@@ -644,7 +644,7 @@ struct PArgs
 // With go <= 0:  m + go + ge <= e <= m + ge  (e = max(sub+go, gap) + ge, m = max(sub, gap)), so d lies in
 // [go + ge, ge] and int16 is exact whenever go + ge >= -32768 (checked on the host).  Each lane owns one dword per
 // cell pair (layout [j/2][thread] dwords, halves by parity of j): conflict-free ds_read_i16 / ds_write_b16.
-template <int W, bool OOB>
+template <int W, bool OOB, int BLOCK>
 __device__ __forceinline__ void prk_band(const PArgs &a, const int *s_tab, short *sD, const int r,
                                          const unsigned (&w)[(2 * W + 1 + 8) / 8 + 2], const int jlo, const int jhi,
                                          int (&M)[2 * W + 1], LaneDP &D)
@@ -672,11 +672,11 @@ __device__ __forceinline__ void prk_band(const PArgs &a, const int *s_tab, short
     {
       const int Pm = M[j];
       int PeNext = NEG;
-      if (j + 1 < B) PeNext = M[j + 1] + (int)myD[((j + 1) >> 1) * 512 + ((j + 1) & 1)];   // previous row's e of cell j+1
+      if (j + 1 < B) PeNext = M[j + 1] + (int)myD[((j + 1) >> 1) * (2 * BLOCK) + ((j + 1) & 1)];   // previous row's e of cell j+1
       int m, e;
       band_step<false, true, OOB, false>(go, ge, W, u, t, Pm, PeNext, D, m, e);
       M[j] = m;
-      myD[(j >> 1) * 512 + (j & 1)] = (short)(e - m);
+      myD[(j >> 1) * (2 * BLOCK) + (j & 1)] = (short)(e - m);
     }
     else
     {
@@ -686,17 +686,17 @@ __device__ __forceinline__ void prk_band(const PArgs &a, const int *s_tab, short
   }
 }
 
-template <int W>
-__global__ __launch_bounds__(256, 2) void ramx_persistent_kernel(const PArgs a)
+template <int W, int BLOCK>
+__global__ __launch_bounds__(BLOCK, 2) void ramx_persistent_kernel(const PArgs a)
 {
-  constexpr int B = 2 * W + 1, Q = W + 1, NW = (B + 8) / 8 + 2;
+  constexpr int B = 2 * W + 1, Q = W + 1, NW = (B + 8) / 8 + 2, WPB = BLOCK / 64, RS = 2 * BLOCK;   // RS: shorts per cell-pair row of sD
   __shared__ __attribute__((aligned(16))) int s_tab[TAB_ROWS * TAB_STRIDE];
-  __shared__ long long s_red[4][4];
+  __shared__ long long s_red[WPB][4];
   __shared__ long long s_vote[4];
   __shared__ int s_fail;
-  __shared__ short sD[((B + 1) / 2) * 512];            // d = e - m, [cell pair][thread][parity]
+  __shared__ short sD[((B + 1) / 2) * RS];            // d = e - m, [cell pair][thread][parity]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int tile = blockIdx.x * 4 + wave;
+  const int tile = blockIdx.x * WPB + wave;
   const bool live = tile < (a.Np >> 6);
   const int n = (live ? tile : 0) * 64 + lane;
   int4 *S = a.S + (size_t)(live ? tile : 0) * Q * 64 + lane;
@@ -711,10 +711,10 @@ __global__ __launch_bounds__(256, 2) void ramx_persistent_kernel(const PArgs a)
     {
       const int4 v = S[(size_t)q * 64];
       M[2 * q] = v.x; M[2 * q + 1] = v.z;
-      myD[q * 512] = (short)(v.y - v.x); myD[q * 512 + 1] = (short)(v.w - v.z);
+      myD[q * RS] = (short)(v.y - v.x); myD[q * RS + 1] = (short)(v.w - v.z);
     }
     const int4 v = S[(size_t)W * 64];
-    M[B - 1] = v.x; myD[W * 512] = (short)(v.y - v.x); high = v.z; pos = v.w;
+    M[B - 1] = v.x; myD[W * RS] = (short)(v.y - v.x); high = v.z; pos = v.w;
   }
   const int2 bd = a.bounds[n];
   const int shard = blockIdx.x % NSHARD;
@@ -820,8 +820,8 @@ __global__ __launch_bounds__(256, 2) void ramx_persistent_kernel(const PArgs a)
 #pragma unroll
       for (int c = 0; c < 4; c++) { D.eA[c] = NEG; D.bestA[c] = NEG; }
       const bool all_in = __all((jlo <= 0) && (jhi >= B));
-      if (all_in) prk_band<W, false>(a, s_tab, sD, r, w, jlo, jhi, M, D);
-      else prk_band<W, true>(a, s_tab, sD, r, w, jlo, jhi, M, D);
+      if (all_in) prk_band<W, false, BLOCK>(a, s_tab, sD, r, w, jlo, jhi, M, D);
+      else prk_band<W, true, BLOCK>(a, s_tab, sD, r, w, jlo, jhi, M, D);
       if (D.bestF > high) { high = D.bestF; pos = r + D.jbest - W; }   // ram_extend.c:1140-1150
       if (new_max) { thigh = high; tpos = pos; }                        // :1203-1207
       if (n < a.Nx)
@@ -846,7 +846,9 @@ __global__ __launch_bounds__(256, 2) void ramx_persistent_kernel(const PArgs a)
     __syncthreads();
     if (threadIdx.x < 4)
     {
-      const long long t = s_red[0][threadIdx.x] + s_red[1][threadIdx.x] + s_red[2][threadIdx.x] + s_red[3][threadIdx.x];
+      long long t = 0;
+#pragma unroll
+      for (int wv = 0; wv < WPB; wv++) t += s_red[wv][threadIdx.x];
       PShard *sh = a.vote + (size_t)((r + 1) % 3) * NSHARD + shard;
       __hip_atomic_fetch_add(&sh->sum[threadIdx.x], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -864,8 +866,8 @@ __global__ __launch_bounds__(256, 2) void ramx_persistent_kernel(const PArgs a)
   {
 #pragma unroll
     for (int q = 0; q < W; q++)
-      S[(size_t)q * 64] = make_int4(M[2 * q], M[2 * q] + (int)myD[q * 512], M[2 * q + 1], M[2 * q + 1] + (int)myD[q * 512 + 1]);
-    S[(size_t)W * 64] = make_int4(M[B - 1], M[B - 1] + (int)myD[W * 512], high, pos);
+      S[(size_t)q * 64] = make_int4(M[2 * q], M[2 * q] + (int)myD[q * RS], M[2 * q + 1], M[2 * q + 1] + (int)myD[q * RS + 1]);
+    S[(size_t)W * 64] = make_int4(M[B - 1], M[B - 1] + (int)myD[W * RS], high, pos);
     a.trim[n] = make_int2(thigh, tpos);
   }
   if (blockIdx.x == 0 && threadIdx.x == 0)
@@ -1054,24 +1056,40 @@ static void launch_column(ramx_dev *d, const KArgs &a)
 }
 
 // ---- persistent path --------------------------------------------------------------------------
-template <int W>
+// Block shape of the persistent launch: at most ONE barrier participant per CU.
+//   <= 4 tiles per CU (N <= 65,536): 256-thread blocks, one wave per SIMD, up to 256 blocks;
+//   otherwise 512-thread blocks (two waves per SIMD), up to 256 blocks = 131,072 flanks.
+template <int W, int BLOCK>
 static int prk_capacity_blocks(int *out)
 {
   int per_cu = 0, dev = 0, cus = 0;
   HIPCHK(hipGetDevice(&dev));
   HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-  HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ramx_persistent_kernel<W>, 256, 0));
-  if (per_cu > 2) per_cu = 2;          // __launch_bounds__(256, 2); the API over-reports by one for SGPR-heavy kernels
+  HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ramx_persistent_kernel<W, BLOCK>, BLOCK, 0));
+  if (per_cu > 1) per_cu = 1;          // one block per CU by design; never trust the API for more
   *out = per_cu * cus;
   return RAMX_OK;
 }
 
-template <int W>
+template <int W, int BLOCK>
 static int prk_launch(ramx_dev *d, PArgs &pa, int blocks)
 {
   void *args[] = { (void *)&pa };
-  HIPCHK(hipLaunchCooperativeKernel((const void *)ramx_persistent_kernel<W>, dim3(blocks), dim3(256), args, 0, d->stream));
+  HIPCHK(hipLaunchCooperativeKernel((const void *)ramx_persistent_kernel<W, BLOCK>, dim3(blocks), dim3(BLOCK), args, 0, d->stream));
   return RAMX_OK;
+}
+
+template <int W>
+static int prk_dispatch(ramx_dev *d, PArgs &pa, int tiles, bool *used)
+{
+  int cap = 0, rc;
+  if ((rc = prk_capacity_blocks<W, 256>(&cap)) != RAMX_OK) return rc;
+  int blocks = (tiles + 3) / 4;
+  if (blocks <= cap) { pa.nblocks = blocks; *used = true; return prk_launch<W, 256>(d, pa, blocks); }
+  if ((rc = prk_capacity_blocks<W, 512>(&cap)) != RAMX_OK) return rc;
+  blocks = (tiles + 7) / 8;
+  if (blocks <= cap) { pa.nblocks = blocks; *used = true; return prk_launch<W, 512>(d, pa, blocks); }
+  return RAMX_OK;                       // not co-resident: the caller keeps the streaming kernel
 }
 
 // which band widths have a register-resident instantiation
@@ -1083,24 +1101,19 @@ static int prk_run(ramx_dev *d, const KArgs &a, int L, bool *used)
   const int W = a.W;
   if (getenv("RAMX_NO_PERSISTENT") != NULL || d->force_chain || a.go > 0 || a.ge > 0 || a.go + a.ge < -32768 || !prk_has_width(W) || L <= 0) return RAMX_OK;
   if ((d->comm != NULL && d->nranks > 1) || d->cb != NULL) return RAMX_OK;
-  const int blocks = (d->Np / 64 + 3) / 4;
-  int cap = 0, rc;
-  rc = (W == 14) ? prk_capacity_blocks<14>(&cap) : (W == 20) ? prk_capacity_blocks<20>(&cap) : prk_capacity_blocks<40>(&cap);
-  if (rc != RAMX_OK) return rc;
-  if (blocks > cap) return RAMX_OK;     // not co-resident: keep the streaming kernel
   PArgs pa;
   memset(&pa, 0, sizeof(pa));
   pa.S = d->d_state[0]; pa.bases = d->d_bases; pa.bounds = d->d_bounds; pa.trim = d->d_trim;
   pa.sums0 = d->d_sums; pa.vote = d->d_vote; pa.ctl_out = d->d_ctl; pa.cons_out = d->d_cons; pa.err = d->d_err;
   pa.Np = d->Np; pa.Nx = d->Nx; pa.r0 = 0; pa.L = L; pa.go = a.go; pa.ge = a.ge; pa.cap = a.cap; pa.minimp = a.minimp;
-  pa.when_to_stop = a.when_to_stop; pa.nblocks = blocks;
+  pa.when_to_stop = a.when_to_stop;
   memcpy(pa.tab, a.tab, sizeof(pa.tab));
+  // the barrier words must be clean even if the launch is not taken
   HIPCHK(hipMemsetAsync(d->d_vote, 0, 3 * NSHARD * sizeof(PShard), d->stream));
   HIPCHK(hipMemsetAsync(d->d_err, 0, 64, d->stream));
-  rc = (W == 14) ? prk_launch<14>(d, pa, blocks) : (W == 20) ? prk_launch<20>(d, pa, blocks) : prk_launch<40>(d, pa, blocks);
-  if (rc != RAMX_OK) return rc;
-  *used = true;
-  return RAMX_OK;
+  const int tiles = d->Np / 64;
+  return (W == 14) ? prk_dispatch<14>(d, pa, tiles, used) : (W == 20) ? prk_dispatch<20>(d, pa, tiles, used)
+                                                                     : prk_dispatch<40>(d, pa, tiles, used);
 }
 
 extern "C" int ramx_dev_run_direction(ramx_dev *d, ramx_run_info *info)
