@@ -608,20 +608,23 @@ __global__ __launch_bounds__(BLOCK) void ramx_column_kernel(const KArgs a)
 // the 32-byte vote.  All L columns run inside one cooperative launch; the dependent-launch boundary of the
 // streaming kernel becomes a device-wide barrier that is fused with the vote:
 //
-//   column c, every block:   4 x int64 atomicAdd of its capped candidate sums into shard (blockIdx % 32) of vote
-//                            set (c+1) % 3, every adding thread drains (vmcnt 0), block barrier, then ONE
-//                            arrival atomic on the shard's counter;
-//   column c+1, wave 0:      lanes 0..31 poll "their" shard's counter (relaxed agent-scope loads + s_sleep,
-//                            bounded) until it shows all of the shard's blocks, read the four sums with
-//                            agent-scope loads, shuffle-reduce, publish vote + score table through LDS.
-//   Set (c+2) % 3 is zeroed by block 0 during column c (everybody finished reading it before arriving for
-//   column c; nobody adds to it before block 0 itself has arrived for column c+1).
+//   column c, every block:   4 x int64 atomicAdd into shard (blockIdx % 32) of vote set (c+1) % 3.  Each add
+//                            carries its own arrival ticket: value = partial_sum + 2^41 + 2^54, so bits 54..63 of
+//                            a shard word count the blocks that have contributed and the low 54 bits hold
+//                            sum + count * 2^41 (|partial| <= 512 lanes * 2^31 < 2^41: exact for any input).
+//   column c+1, wave 0:      lanes 0..31 poll "their" shard's four words (relaxed agent-scope loads + s_sleep,
+//                            bounded) until all four show every block of the shard, decode, shuffle-reduce and
+//                            publish the vote through LDS.  One fabric round trip after the last arrival.
+//   Set (c+2) % 3 is zeroed by block 0 during column c, before block 0's own adds (everybody finished reading it
+//   before contributing to column c; nobody adds to it before block 0 itself has contributed to column c+1).
 //
 // Placement independent: only agent-scope atomics / atomic loads touch shared words, no assumption on which
 // XCD a block runs; co-residency is checked by hipLaunchCooperativeKernel and every spin is bounded (a timeout
 // raises `err` and every block leaves).  Multi-GPU runs keep the per-column launches (RCCL sits between them).
 
-struct PShard { long long sum[4]; unsigned cnt; unsigned pad[7]; };   // 64 B: one cache line per shard
+struct PShard { unsigned long long word[4]; unsigned long long pad[4]; };   // 64 B: one cache line per shard
+#define PRK_BIAS (1ULL << 41)
+#define PRK_TICKET (1ULL << 54)
 
 struct PArgs
 {
@@ -690,7 +693,7 @@ template <int W, int BLOCK>
 __global__ __launch_bounds__(BLOCK, 2) void ramx_persistent_kernel(const PArgs a)
 {
   constexpr int B = 2 * W + 1, Q = W + 1, NW = (B + 8) / 8 + 2, WPB = BLOCK / 64, RS = 2 * BLOCK;   // RS: shorts per cell-pair row of sD
-  __shared__ __attribute__((aligned(16))) int s_tab[TAB_ROWS * TAB_STRIDE];
+  __shared__ __attribute__((aligned(16))) int s_tab4[4][TAB_ROWS * TAB_STRIDE];   // one score table per winner base
   __shared__ long long s_red[WPB][4];
   __shared__ long long s_vote[4];
   __shared__ int s_fail;
@@ -723,6 +726,13 @@ __global__ __launch_bounds__(BLOCK, 2) void ramx_persistent_kernel(const PArgs a
   long long max_ext = 0;
   int max_row = -1, rows_done = 0, ovf = 0, stopped = 0, failed = 0;
   if (threadIdx.x == 0) s_fail = 0;
+  for (int i = threadIdx.x; i < 4 * TAB_ROWS * TAB_STRIDE; i += BLOCK)
+  {
+    const int bt = i / (TAB_ROWS * TAB_STRIDE), e = i % (TAB_ROWS * TAB_STRIDE), row = e / TAB_STRIDE, col = e % TAB_STRIDE;
+    int v = 0;
+    if (row < RAMX_NCLASS) v = (col < 4) ? a.tab[row][col] : (col == 4 ? a.tab[row][bt] : 0);
+    s_tab4[bt][e] = v;
+  }
 
   for (int r = 0; r < a.L; r++)
   {
@@ -745,22 +755,30 @@ __global__ __launch_bounds__(BLOCK, 2) void ramx_persistent_kernel(const PArgs a
       {
         PShard *sh = a.vote + (size_t)(r % 3) * NSHARD + (lane < NSHARD ? lane : 0);
         unsigned spins = 0;
-        bool done = lane >= NSHARD;
+        bool done = lane >= NSHARD || my_shard_blocks <= 0;
+        unsigned long long x[4] = { 0, 0, 0, 0 };
         for (;;)
         {
-          if (!done) done = __hip_atomic_load(&sh->cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)my_shard_blocks;
+          if (!done)
+          {
+#pragma unroll
+            for (int k = 0; k < 4; k++) x[k] = __hip_atomic_load(&sh->word[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            done = (x[0] >> 54) >= (unsigned long long)my_shard_blocks && (x[1] >> 54) >= (unsigned long long)my_shard_blocks &&
+                   (x[2] >> 54) >= (unsigned long long)my_shard_blocks && (x[3] >> 54) >= (unsigned long long)my_shard_blocks;
+          }
           if (__all(done)) break;
           if (++spins > PRK_SPIN_LIMIT || ((spins & 1023u) == 0 && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0))
           {
             failed = 1;
             break;
           }
-          __builtin_amdgcn_s_sleep(2);
+          __builtin_amdgcn_s_sleep(1);
         }
-        if (lane < NSHARD && !failed)
+        if (lane < NSHARD && my_shard_blocks > 0 && !failed)
         {
 #pragma unroll
-          for (int k = 0; k < 4; k++) v[k] = __hip_atomic_load(&sh->sum[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          for (int k = 0; k < 4; k++)
+            v[k] = (long long)(x[k] & (PRK_TICKET - 1)) - (long long)(x[k] >> 54) * (long long)PRK_BIAS;
         }
       }
 #pragma unroll
@@ -797,18 +815,9 @@ __global__ __launch_bounds__(BLOCK, 2) void ramx_persistent_kernel(const PArgs a
     {
       PShard *z = a.vote + (size_t)((r + 2) % 3) * NSHARD + threadIdx.x;
 #pragma unroll
-      for (int k = 0; k < 4; k++) __hip_atomic_store(&z->sum[k], 0LL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(&z->cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int k = 0; k < 4; k++) __hip_atomic_store(&z->word[k], 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    // score table (column 4 follows besta)
-    if (threadIdx.x < TAB_ROWS * TAB_STRIDE)
-    {
-      const int row = threadIdx.x / TAB_STRIDE, col = threadIdx.x % TAB_STRIDE;
-      int v = 0;
-      if (row < RAMX_NCLASS) v = (col < 4) ? a.tab[row][col] : (col == 4 ? a.tab[row][besta] : 0);
-      s_tab[threadIdx.x] = v;
-    }
-    __syncthreads();
+    const int *s_tab = s_tab4[besta];                // column 4 of table `besta` holds M[besta][class]
 
     // ---- the band, rows in registers ---------------------------------------------------------
     long long contrib[4] = { 0, 0, 0, 0 };
@@ -844,20 +853,15 @@ __global__ __launch_bounds__(BLOCK, 2) void ramx_persistent_kernel(const PArgs a
       for (int c = 0; c < 4; c++) s_red[wave][c] = contrib[c];
     }
     __syncthreads();
+    if (blockIdx.x == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // block 0: its zeroing stores first
     if (threadIdx.x < 4)
     {
       long long t = 0;
 #pragma unroll
       for (int wv = 0; wv < WPB; wv++) t += s_red[wv][threadIdx.x];
       PShard *sh = a.vote + (size_t)((r + 1) % 3) * NSHARD + shard;
-      __hip_atomic_fetch_add(&sh->sum[threadIdx.x], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // every adding / zeroing thread drains before the arrival
-    __syncthreads();
-    if (threadIdx.x == 0)
-    {
-      PShard *sh = a.vote + (size_t)((r + 1) % 3) * NSHARD + shard;
-      __hip_atomic_fetch_add(&sh->cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(&sh->word[threadIdx.x], (unsigned long long)t + PRK_BIAS + PRK_TICKET, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 
