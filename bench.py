@@ -114,13 +114,35 @@ def main():
 
     ndev = max(_lib.lib().ramx_device_count(), 1)
     dev = Device(local_rank % ndev)     # (% ndev only matters when ranks are over-subscribed on purpose in tests)
+    peer_path = False
     if world > 1:
         on = "cuda" if dist.get_backend() == "nccl" else "cpu"
-        uid = torch.zeros(128, dtype=torch.uint8, device=on)
-        if rank == 0:
-            uid = torch.from_numpy(dev.unique_id().copy()).to(on)
-        dist.broadcast(uid, 0)
-        dev.comm_init(uid.cpu().numpy(), rank, world)
+        if dist.get_backend() == "nccl":
+            uid = torch.zeros(128, dtype=torch.uint8, device=on)
+            if rank == 0:
+                uid = torch.from_numpy(dev.unique_id().copy()).to(on)
+            dist.broadcast(uid, 0)
+            dev.comm_init(uid.cpu().numpy(), rank, world)       # RCCL communicator inside libramx
+        else:
+            # 1-GPU rehearsal only (RCCL refuses two ranks per device): host collectives through gloo
+            def _cb(v):
+                t = torch.tensor(v, dtype=torch.int64)
+                dist.all_reduce(t)
+                return t.tolist()
+            dev.set_allreduce_callback(_cb)
+
+        def ag_bytes(b):
+            t = torch.frombuffer(bytearray(b), dtype=torch.uint8).to(on)
+            outs = [torch.zeros(64, dtype=torch.uint8, device=on) for _ in range(world)]
+            dist.all_gather(outs, t)
+            return [bytes(o.cpu().numpy().tobytes()) for o in outs]
+
+        def ar_min(v):
+            t = torch.tensor([v], dtype=torch.int64, device=on)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return int(t.item())
+        if os.environ.get("RAMX_NO_PEER") is None:
+            peer_path = dev.peer_setup(rank, world, ag_bytes, ar_min, dist.barrier)   # vote over xGMI from inside the kernel
     t0 = time.time()
     dev.load_library(fs.sequence)
     flanks, idx = resolve_flanks(1, fs.cores, W, L)
@@ -186,7 +208,9 @@ def main():
         "config": {"workload": f"synthetic N={N} flanks/GPU x L={L} bp, bandwidth={W}, matrix 14p43g, "
                                f"K=1500 @14% divergence, right extension, stopafter=L (all L columns)",
                    "flanks_total": total_flanks, "columns_per_step": cols // max(args.steps, 1),
-                   "parallelism": f"flank-sharded x{world}, 4xint64 all-reduce per column" if world > 1 else "single GPU"},
+                   "parallelism": (f"flank-sharded x{world}, per-column vote "
+                                   + ("exchanged over xGMI inside the persistent kernels (peer mailboxes)" if (peer_path and persistent)
+                                      else "all-reduced with RCCL between column launches")) if world > 1 else "single GPU"},
         "columns_per_sec": cols / dt,
         "cell_updates_per_sec": cols / dt * total_flanks * (2 * W + 1) * 4,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -200,6 +200,17 @@ int ramx_dev_peek_state(ramx_dev *d, int32_t flank, int32_t *cells, int32_t *hig
  * (ramx_comm_unique_id) and handed to the other ranks by the launcher (e.g. torch.distributed). */
 int ramx_comm_unique_id(uint8_t id[128]);
 int ramx_dev_comm_init(ramx_dev *d, const uint8_t id[128], int rank, int nranks);
+/* Cross-device persistent path (optional, faster than one RCCL call per column): every rank exports the IPC handle
+ * of its mailbox (64 bytes), the launcher all-gathers the handles, every rank imports them; a two-phase self-test
+ * (phase 0: write tokens into all boxes -- synchronise the ranks -- phase 1: returns 1 if every rank's token arrived)
+ * lets the launcher enable the path only if it works on ALL ranks.  With the path enabled the whole direction runs
+ * as one persistent launch per rank and the per-column vote travels over xGMI from inside the kernels; if any rank
+ * gives up (bounded spins) all ranks repeat the direction with per-column launches + RCCL. */
+int ramx_dev_peer_export(ramx_dev *d, uint8_t handle[64]);
+int ramx_dev_peer_import(ramx_dev *d, const uint8_t *handles /* [nranks][64] */, int rank, int nranks);
+int ramx_dev_peer_selftest(ramx_dev *d, int phase, unsigned long long token);
+int ramx_dev_peer_enable(ramx_dev *d, int on);
+
 /* test hook: replaces RCCL by a caller-supplied all-reduce so the sharded control flow (fold kernel, reduced
  * vote consumed by the next column, replicated stop rule) can be exercised where RCCL cannot run, e.g. two
  * ranks sharing the single GPU of a test box.  cb must sum 4 int64 in place across ranks and block until

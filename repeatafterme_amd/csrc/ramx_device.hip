@@ -626,6 +626,16 @@ struct PShard { unsigned long long word[4]; unsigned long long pad[4]; };   // 6
 #define PRK_BIAS (1ULL << 41)
 #define PRK_TICKET (1ULL << 54)
 
+// Multi-GPU: every rank owns one PeerBox in fine-grained device memory, mapped into all other ranks through
+// hipIpc handles.  After a rank's own blocks have all contributed to a column, its block 0 stores the rank's four
+// totals into slot [set][rank] of EVERY box (its own included) over xGMI; each word carries the column number in
+// its top 16 bits, so a reader knows a word is current without any flag or fence; every block then polls the local
+// box until all ranks' words of this column are there.  3 sets rotate exactly like the vote shards.
+#define RAMX_MAX_RANKS 16
+struct PeerBox { unsigned long long slot[3][RAMX_MAX_RANKS][4]; unsigned long long token[RAMX_MAX_RANKS]; };
+#define PEER_VBIAS (1LL << 46)
+#define PEER_VMASK ((1ULL << 48) - 1)
+
 struct PArgs
 {
   int4 *S;                      // row state in HBM: read at start (boundary row from K(-1)), written back at the end
@@ -637,6 +647,9 @@ struct PArgs
   RamxCtl *ctl_out;
   signed char *cons_out;
   unsigned *err;                // != 0: a bounded spin gave up
+  PeerBox *const *peers;        // [nranks] every rank's box as seen from this device (NULL on one GPU)
+  PeerBox *box;                 // this rank's own box
+  int rank, nranks;
   int Np, Nx, r0, L, go, ge, cap, minimp, when_to_stop, nblocks;
   int tab[RAMX_NCLASS][4];
 };
@@ -755,7 +768,7 @@ __global__ __launch_bounds__(BLOCK, 2) void ramx_persistent_kernel(const PArgs a
       {
         PShard *sh = a.vote + (size_t)(r % 3) * NSHARD + (lane < NSHARD ? lane : 0);
         unsigned spins = 0;
-        bool done = lane >= NSHARD || my_shard_blocks <= 0;
+        bool done = lane >= NSHARD || my_shard_blocks <= 0 || (a.nranks > 1 && blockIdx.x != 0);   // multi-rank: only the exchanger needs the local total
         unsigned long long x[4] = { 0, 0, 0, 0 };
         for (;;)
         {
@@ -774,7 +787,7 @@ __global__ __launch_bounds__(BLOCK, 2) void ramx_persistent_kernel(const PArgs a
           }
           __builtin_amdgcn_s_sleep(1);
         }
-        if (lane < NSHARD && my_shard_blocks > 0 && !failed)
+        if (lane < NSHARD && my_shard_blocks > 0 && !failed && !(a.nranks > 1 && blockIdx.x != 0))
         {
 #pragma unroll
           for (int k = 0; k < 4; k++)
@@ -783,6 +796,45 @@ __global__ __launch_bounds__(BLOCK, 2) void ramx_persistent_kernel(const PArgs a
       }
 #pragma unroll
       for (int k = 0; k < 4; k++) v[k] = wave_sum_ll(v[k]);
+      if (a.nranks > 1 && r > 0 && !failed)
+      {
+        // ---- cross-device step: v[] is this rank's total (identical in all lanes) -----------
+        const unsigned long long tag = (unsigned long long)(r & 0xffff) << 48;
+        if (blockIdx.x == 0 && lane < a.nranks)
+        {
+          PeerBox *pb = a.peers[lane];
+#pragma unroll
+          for (int k = 0; k < 4; k++)
+          {
+            if (v[k] >= PEER_VBIAS || v[k] <= -PEER_VBIAS) failed = 1;     // cannot be encoded: fail loudly
+            __hip_atomic_store(&pb->slot[r % 3][a.rank][k], tag | ((unsigned long long)(v[k] + PEER_VBIAS) & PEER_VMASK),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          }
+        }
+        unsigned long long y[4] = { 0, 0, 0, 0 };
+        bool got = lane >= a.nranks;
+        unsigned spins = 0;
+        for (;;)
+        {
+          if (!got)
+          {
+#pragma unroll
+            for (int k = 0; k < 4; k++) y[k] = __hip_atomic_load(&a.box->slot[r % 3][lane][k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            got = (y[0] >> 48) == (tag >> 48) && (y[1] >> 48) == (tag >> 48) && (y[2] >> 48) == (tag >> 48) && (y[3] >> 48) == (tag >> 48);
+          }
+          if (__all(got)) break;
+          if (++spins > PRK_SPIN_LIMIT || ((spins & 1023u) == 0 && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0))
+          {
+            failed = 1;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+        failed = __any(failed) ? 1 : 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+          v[k] = wave_sum_ll((lane < a.nranks && !failed) ? (long long)(y[k] & PEER_VMASK) - PEER_VBIAS : 0LL);
+      }
       if (lane == 0)
       {
         s_vote[0] = v[0]; s_vote[1] = v[1]; s_vote[2] = v[2]; s_vote[3] = v[3];
@@ -906,6 +958,8 @@ struct ramx_dev
   // multi-GPU
   ncclComm_t comm; int rank, nranks;
   ramx_allreduce_cb cb; void *cb_user;
+  // cross-device persistent path: this rank's box (fine-grained), every rank's box as mapped here, device copy of that table
+  PeerBox *xbox; PeerBox *peer[RAMX_MAX_RANKS]; PeerBox **d_peer; int peer_ready;
   int force_chain;   // RAMX_FORCE_CHAIN=1: always run the full candidate recurrence (test hook)
 };
 
@@ -934,7 +988,7 @@ extern "C" int ramx_dev_create(int ordinal, ramx_dev **out)
   d->ordinal = ordinal;
   HIPCHK(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
   HIPCHK(hipHostMalloc((void **)&d->h_ctl, 4 * sizeof(RamxCtl), hipHostMallocDefault));
-  HIPCHK(hipMalloc((void **)&d->d_sums, 3 * NSHARD * 4 * sizeof(long long)));
+  HIPCHK(hipMalloc((void **)&d->d_sums, (3 * NSHARD * 4 + 8) * sizeof(long long)));
   HIPCHK(hipMalloc((void **)&d->d_ctl, 2 * sizeof(RamxCtl)));
   HIPCHK(hipMalloc((void **)&d->d_vote, 3 * NSHARD * sizeof(PShard)));
   HIPCHK(hipMalloc((void **)&d->d_err, 64));
@@ -1059,6 +1113,128 @@ static void launch_column(ramx_dev *d, const KArgs &a)
     hipLaunchKernelGGL((ramx_column_kernel<INIT, true, 256>), grid, block, 0, d->stream, a);
 }
 
+// ---- host-side collective on 4 x int64 in device memory (RCCL, or the test hook) ---------------
+static int host_allreduce_shards(ramx_dev *d, long long *dptr)   // dptr: NSHARD x 4 int64, summed over ranks in place
+{
+  if (d->cb)
+  {
+    long long h[NSHARD * 4], h4[4] = { 0, 0, 0, 0 };
+    HIPCHK(hipMemcpyAsync(h, dptr, sizeof(h), hipMemcpyDeviceToHost, d->stream));
+    HIPCHK(hipStreamSynchronize(d->stream));
+    for (int i = 0; i < NSHARD * 4; i++) h4[i & 3] += h[i];
+    d->cb(h4, d->cb_user);
+    memset(h, 0, sizeof(h));
+    memcpy(h, h4, sizeof(h4));
+    HIPCHK(hipMemcpyAsync(dptr, h, sizeof(h), hipMemcpyHostToDevice, d->stream));
+    HIPCHK(hipStreamSynchronize(d->stream));
+    return RAMX_OK;
+  }
+  ncclResult_t nr = ncclAllReduce(dptr, dptr, NSHARD * 4, ncclInt64, ncclSum, d->comm, d->stream);
+  if (nr != ncclSuccess) { ramx_set_error("ncclAllReduce: %s", ncclGetErrorString(nr)); return RAMX_ERR_COMM; }
+  return RAMX_OK;
+}
+
+// one small integer agreed over all ranks (max): used to agree on a fallback
+static int host_allreduce_flag(ramx_dev *d, int *flag)
+{
+  if (d->cb)
+  {
+    long long h4[4] = { *flag ? 1 : 0, 0, 0, 0 };
+    d->cb(h4, d->cb_user);
+    *flag = h4[0] != 0;
+    return RAMX_OK;
+  }
+  long long *tmp = d->d_sums + 3 * NSHARD * 4;   // spare 4 words behind the three vote slots
+  long long h = *flag ? 1 : 0;
+  HIPCHK(hipMemcpyAsync(tmp, &h, sizeof(h), hipMemcpyHostToDevice, d->stream));
+  ncclResult_t nr = ncclAllReduce(tmp, tmp, 1, ncclInt64, ncclMax, d->comm, d->stream);
+  if (nr != ncclSuccess) { ramx_set_error("ncclAllReduce: %s", ncclGetErrorString(nr)); return RAMX_ERR_COMM; }
+  HIPCHK(hipMemcpyAsync(&h, tmp, sizeof(h), hipMemcpyDeviceToHost, d->stream));
+  HIPCHK(hipStreamSynchronize(d->stream));
+  *flag = h != 0;
+  return RAMX_OK;
+}
+
+// ---- peer boxes ------------------------------------------------------------------------------------
+extern "C" int ramx_dev_peer_export(ramx_dev *d, uint8_t handle[64])
+{
+  if (!d || !handle) { ramx_set_error("ramx_dev_peer_export: bad argument"); return RAMX_ERR_ARG; }
+  HIPCHK(hipSetDevice(d->ordinal));
+  if (!d->xbox)
+  {
+    hipError_t e = hipExtMallocWithFlags((void **)&d->xbox, sizeof(PeerBox), hipDeviceMallocFinegrained);
+    if (e != hipSuccess) { d->xbox = NULL; ramx_set_error("fine-grained allocation for the peer box failed: %s", hipGetErrorString(e)); return RAMX_ERR_HIP; }
+    HIPCHK(hipMemset(d->xbox, 0, sizeof(PeerBox)));
+  }
+  hipIpcMemHandle_t h;
+  HIPCHK(hipIpcGetMemHandle(&h, d->xbox));
+  static_assert(sizeof(hipIpcMemHandle_t) <= 64, "ipc handle size");
+  memset(handle, 0, 64);
+  memcpy(handle, &h, sizeof(h));
+  return RAMX_OK;
+}
+
+__global__ void ramx_peer_token_kernel(PeerBox *const *peers, int rank, int nranks, unsigned long long token)
+{
+  if (threadIdx.x < nranks)
+    __hip_atomic_store(&peers[threadIdx.x]->token[rank], token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+extern "C" int ramx_dev_peer_import(ramx_dev *d, const uint8_t *handles, int rank, int nranks)
+{
+  if (!d || !handles || rank < 0 || rank >= nranks || nranks > RAMX_MAX_RANKS || !d->xbox)
+  { ramx_set_error("ramx_dev_peer_import: bad argument (export first; at most %d ranks)", RAMX_MAX_RANKS); return RAMX_ERR_ARG; }
+  HIPCHK(hipSetDevice(d->ordinal));
+  d->peer_ready = 0;
+  d->rank = rank; d->nranks = nranks;
+  for (int q = 0; q < nranks; q++)
+  {
+    if (q == rank) { d->peer[q] = d->xbox; continue; }
+    hipIpcMemHandle_t h;
+    memcpy(&h, handles + 64 * q, sizeof(h));
+    void *ptr = NULL;
+    hipError_t e = hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) { ramx_set_error("hipIpcOpenMemHandle(rank %d): %s", q, hipGetErrorString(e)); return RAMX_ERR_HIP; }
+    d->peer[q] = (PeerBox *)ptr;
+  }
+  if (!d->d_peer) HIPCHK(hipMalloc((void **)&d->d_peer, RAMX_MAX_RANKS * sizeof(PeerBox *)));
+  HIPCHK(hipMemcpy(d->d_peer, d->peer, nranks * sizeof(PeerBox *), hipMemcpyHostToDevice));
+  return RAMX_OK;
+}
+
+/* self-test of the mapped boxes: write a token into every rank's box, then (after the caller has synchronised the
+ * ranks) check that every rank's token arrived here.  phase 0 = write, phase 1 = check (returns 1 if all there). */
+extern "C" int ramx_dev_peer_selftest(ramx_dev *d, int phase, unsigned long long token)
+{
+  if (!d || !d->d_peer) { ramx_set_error("ramx_dev_peer_selftest: import first"); return RAMX_ERR_ARG; }
+  HIPCHK(hipSetDevice(d->ordinal));
+  if (phase == 0)
+  {
+    hipLaunchKernelGGL(ramx_peer_token_kernel, dim3(1), dim3(64), 0, d->stream, (PeerBox *const *)d->d_peer, d->rank, d->nranks, token);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(d->stream));
+    return RAMX_OK;
+  }
+  PeerBox h;
+  for (int tries = 0; tries < 200; tries++)
+  {
+    HIPCHK(hipMemcpy(&h, d->xbox, sizeof(h), hipMemcpyDeviceToHost));
+    int ok = 1;
+    for (int q = 0; q < d->nranks; q++) ok &= (h.token[q] == token);
+    if (ok) return 1;
+    struct timespec ts = { 0, 1000000 };
+    nanosleep(&ts, NULL);
+  }
+  return 0;
+}
+
+extern "C" int ramx_dev_peer_enable(ramx_dev *d, int on)
+{
+  if (!d) return RAMX_ERR_ARG;
+  d->peer_ready = (on && d->d_peer && d->xbox) ? 1 : 0;
+  return RAMX_OK;
+}
+
 // ---- persistent path --------------------------------------------------------------------------
 // Block shape of the persistent launch: at most ONE barrier participant per CU.
 //   <= 4 tiles per CU (N <= 65,536): 256-thread blocks, one wave per SIMD, up to 256 blocks;
@@ -1083,17 +1259,17 @@ static int prk_launch(ramx_dev *d, PArgs &pa, int blocks)
   return RAMX_OK;
 }
 
+// block shape that keeps the whole flank set resident, or 0
 template <int W>
-static int prk_dispatch(ramx_dev *d, PArgs &pa, int tiles, bool *used)
+static int prk_plan(int tiles, int *block, int *blocks)
 {
   int cap = 0, rc;
+  *block = 0; *blocks = 0;
   if ((rc = prk_capacity_blocks<W, 256>(&cap)) != RAMX_OK) return rc;
-  int blocks = (tiles + 3) / 4;
-  if (blocks <= cap) { pa.nblocks = blocks; *used = true; return prk_launch<W, 256>(d, pa, blocks); }
+  if ((tiles + 3) / 4 <= cap) { *block = 256; *blocks = (tiles + 3) / 4; return RAMX_OK; }
   if ((rc = prk_capacity_blocks<W, 512>(&cap)) != RAMX_OK) return rc;
-  blocks = (tiles + 7) / 8;
-  if (blocks <= cap) { pa.nblocks = blocks; *used = true; return prk_launch<W, 512>(d, pa, blocks); }
-  return RAMX_OK;                       // not co-resident: the caller keeps the streaming kernel
+  if ((tiles + 7) / 8 <= cap) { *block = 512; *blocks = (tiles + 7) / 8; }
+  return RAMX_OK;
 }
 
 // which band widths have a register-resident instantiation
@@ -1103,21 +1279,48 @@ static int prk_run(ramx_dev *d, const KArgs &a, int L, bool *used)
 {
   *used = false;
   const int W = a.W;
-  if (getenv("RAMX_NO_PERSISTENT") != NULL || d->force_chain || a.go > 0 || a.ge > 0 || a.go + a.ge < -32768 || !prk_has_width(W) || L <= 0) return RAMX_OK;
-  if ((d->comm != NULL && d->nranks > 1) || d->cb != NULL) return RAMX_OK;
+  const bool multi = (d->comm != NULL && d->nranks > 1) || d->cb != NULL;
+  const int tiles = d->Np / 64;
+  int block = 0, blocks = 0, rc;
+  bool can = !(getenv("RAMX_NO_PERSISTENT") != NULL || d->force_chain || a.go > 0 || a.ge > 0 || a.go + a.ge < -32768 ||
+               !prk_has_width(W) || L <= 0);
+  if (multi && (!d->peer_ready || d->nranks < 2 || L >= 65536 || getenv("RAMX_NO_PEER") != NULL)) can = false;
+  if (can)
+  {
+    rc = (W == 14) ? prk_plan<14>(tiles, &block, &blocks) : (W == 20) ? prk_plan<20>(tiles, &block, &blocks) : prk_plan<40>(tiles, &block, &blocks);
+    if (rc != RAMX_OK) return rc;
+    if (block == 0) can = false;          // not co-resident: keep the streaming kernel
+  }
+  if (multi)
+  {
+    // every rank must take the same path: agree (max over ranks of "cannot")
+    int cannot = can ? 0 : 1;
+    if ((rc = host_allreduce_flag(d, &cannot)) != RAMX_OK) return rc;
+    can = !cannot;
+  }
+  if (!can) return RAMX_OK;
   PArgs pa;
   memset(&pa, 0, sizeof(pa));
   pa.S = d->d_state[0]; pa.bases = d->d_bases; pa.bounds = d->d_bounds; pa.trim = d->d_trim;
   pa.sums0 = d->d_sums; pa.vote = d->d_vote; pa.ctl_out = d->d_ctl; pa.cons_out = d->d_cons; pa.err = d->d_err;
   pa.Np = d->Np; pa.Nx = d->Nx; pa.r0 = 0; pa.L = L; pa.go = a.go; pa.ge = a.ge; pa.cap = a.cap; pa.minimp = a.minimp;
-  pa.when_to_stop = a.when_to_stop;
+  pa.when_to_stop = a.when_to_stop; pa.nblocks = blocks;
+  pa.nranks = 1; pa.rank = 0; pa.peers = NULL; pa.box = NULL;
+  if (multi)
+  {
+    pa.nranks = d->nranks; pa.rank = d->rank; pa.peers = (PeerBox *const *)d->d_peer; pa.box = d->xbox;
+    // my box is cleared BEFORE the collective below, which no remote launch can get past without my taking part:
+    // nobody writes a word of this run into it too early, and nothing of the last run survives
+    HIPCHK(hipMemsetAsync(d->xbox, 0, sizeof(PeerBox), d->stream));
+    if ((rc = host_allreduce_shards(d, d->d_sums)) != RAMX_OK) return rc;     // vote of row 0 (from K(-1)) over ranks
+  }
   memcpy(pa.tab, a.tab, sizeof(pa.tab));
-  // the barrier words must be clean even if the launch is not taken
   HIPCHK(hipMemsetAsync(d->d_vote, 0, 3 * NSHARD * sizeof(PShard), d->stream));
   HIPCHK(hipMemsetAsync(d->d_err, 0, 64, d->stream));
-  const int tiles = d->Np / 64;
-  return (W == 14) ? prk_dispatch<14>(d, pa, tiles, used) : (W == 20) ? prk_dispatch<20>(d, pa, tiles, used)
-                                                                     : prk_dispatch<40>(d, pa, tiles, used);
+  *used = true;
+  if (block == 256)
+    return (W == 14) ? prk_launch<14, 256>(d, pa, blocks) : (W == 20) ? prk_launch<20, 256>(d, pa, blocks) : prk_launch<40, 256>(d, pa, blocks);
+  return (W == 14) ? prk_launch<14, 512>(d, pa, blocks) : (W == 20) ? prk_launch<20, 512>(d, pa, blocks) : prk_launch<40, 512>(d, pa, blocks);
 }
 
 extern "C" int ramx_dev_run_direction(ramx_dev *d, ramx_run_info *info)
@@ -1150,6 +1353,27 @@ extern "C" int ramx_dev_run_direction(ramx_dev *d, ramx_run_info *info)
     if (d->d_state[0] != d->d_state[1]) { ramx_set_error("persistent path needs the in-place row buffer"); }
     else { int prc = prk_run(d, a, L, &persistent); if (prc != RAMX_OK) return prc; }
   }
+  if (persistent && multi)
+  {
+    // agree over all ranks whether the cross-device launch went through; if any rank gave up (bounded spin), every
+    // rank repeats the direction with the per-column launches and the host collective
+    HIPCHK(hipStreamSynchronize(d->stream));
+    RamxCtl c0;
+    HIPCHK(hipMemcpy(&c0, d->d_ctl, sizeof(c0), hipMemcpyDeviceToHost));
+    int bad = c0.pad != 0;
+    int frc = host_allreduce_flag(d, &bad);
+    if (frc != RAMX_OK) return frc;
+    if (bad)
+    {
+      fprintf(stderr, "ramx: cross-device persistent launch gave up on some rank; repeating the direction with per-column launches\n");
+      persistent = false;
+      HIPCHK(hipMemsetAsync(d->d_sums, 0, 3 * NSHARD * 4 * sizeof(long long), d->stream));
+      a.r = -1; a.S_in = d->d_state[0]; a.S_out = d->d_state[1]; a.ctl_in = d->d_ctl; a.ctl_out = d->d_ctl + 1;
+      a.sums_in = slot(0); a.sums_out = slot(0); a.sums_zero = slot(1); a.nshards_in = NSHARD;
+      launch_column<true>(d, a);
+      HIPCHK(hipMemsetAsync(d->d_ctl, 0, sizeof(RamxCtl), d->stream));
+    }
+  }
   d->last_persistent = persistent ? 1 : 0;
   const int CHUNK = 64;
   const int stride = L > MAX_SAMPLES * 4 ? L / MAX_SAMPLES : 4;
@@ -1161,23 +1385,8 @@ extern "C" int ramx_dev_run_direction(ramx_dev *d, ramx_run_info *info)
     {
       // the vote shards of row r (32 x 4 x int64 = 1 KB) are summed across ranks in place; the column kernel then
       // folds them exactly as in the single-GPU case.  One collective per column, no extra kernel.
-      if (d->cb)
-      {
-        long long h[NSHARD * 4], h4[4] = { 0, 0, 0, 0 };
-        HIPCHK(hipMemcpyAsync(h, slot(r), sizeof(h), hipMemcpyDeviceToHost, d->stream));
-        HIPCHK(hipStreamSynchronize(d->stream));
-        for (int i = 0; i < NSHARD * 4; i++) h4[i & 3] += h[i];
-        d->cb(h4, d->cb_user);
-        memset(h, 0, sizeof(h));
-        memcpy(h, h4, sizeof(h4));
-        HIPCHK(hipMemcpyAsync(slot(r), h, sizeof(h), hipMemcpyHostToDevice, d->stream));
-        HIPCHK(hipStreamSynchronize(d->stream));
-      }
-      else
-      {
-        ncclResult_t nr = ncclAllReduce(slot(r), slot(r), NSHARD * 4, ncclInt64, ncclSum, d->comm, d->stream);
-        if (nr != ncclSuccess) { ramx_set_error("ncclAllReduce: %s", ncclGetErrorString(nr)); return RAMX_ERR_COMM; }
-      }
+      int hrc = host_allreduce_shards(d, slot(r));
+      if (hrc != RAMX_OK) return hrc;
     }
     a.sums_in = slot(r); a.nshards_in = NSHARD;
     a.r = r; a.S_in = d->d_state[(r + 1) & 1]; a.S_out = d->d_state[r & 1];

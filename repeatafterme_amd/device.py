@@ -96,3 +96,27 @@ class Device:
                 ptr[i] = int(vals[i])
         self._cb = _lib.ALLREDUCE_CB(_cb)      # keep the trampoline alive
         _lib.check(self._L.ramx_dev_set_allreduce_cb(self._h, self._cb, None), "ramx_dev_set_allreduce_cb")
+
+    def peer_setup(self, rank: int, world: int, all_gather_bytes, all_reduce_min, barrier) -> bool:
+        """Cross-device persistent path (ramx_dev_peer_*): exchange the mailbox IPC handles, self-test, enable the
+        path only if it works on every rank.  all_gather_bytes(bytes64) -> list of world bytes objects;
+        all_reduce_min(int) -> int; barrier() -> None.  Returns whether the path is enabled."""
+        ok = 1
+        h = np.zeros(64, np.uint8)
+        if self._L.ramx_dev_peer_export(self._h, h.ctypes.data) < 0:
+            ok = 0
+        handles = all_gather_bytes(h.tobytes())
+        if all_reduce_min(ok) == 1:
+            allh = np.frombuffer(b"".join(handles), np.uint8).copy()
+            if self._L.ramx_dev_peer_import(self._h, allh.ctypes.data, rank, world) < 0:
+                ok = 0
+        if all_reduce_min(ok) == 1:
+            token = 0x52414D58000000 + world
+            if self._L.ramx_dev_peer_selftest(self._h, 0, token) < 0:
+                ok = 0
+            barrier()
+            if ok and self._L.ramx_dev_peer_selftest(self._h, 1, token) != 1:
+                ok = 0
+        ok = all_reduce_min(ok)
+        self._L.ramx_dev_peer_enable(self._h, int(ok == 1))
+        return ok == 1

@@ -21,7 +21,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, peer=False, W=20):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -46,17 +46,30 @@ def _worker(rank, world, port, out):
         dist.all_gather(outs, buf)
         return np.concatenate([o[:int(s.item())].numpy() for o, s in zip(outs, sizes)])
 
-    fs = synth_family(333, 150, 20, K=100, seed=12, both_sides=True, minus_frac=0.3, n_run_frac=0.1)
-    p = po.Params.named("14p43g", bandwidth=20, L=150, when_to_stop=25)
+    fs = synth_family(333, 150, W, K=100, seed=12, both_sides=True, minus_frac=0.3, n_run_frac=0.1)
+    p = po.Params.named("14p43g", bandwidth=W, L=150, when_to_stop=25)
     dev = Device(0)
     dev.set_allreduce_callback(allreduce4)
+    enabled = False
+    if peer:
+        def ag_bytes(b):
+            lst = [None] * world
+            dist.all_gather_object(lst, b)
+            return lst
+
+        def ar_min(v):
+            t = torch.tensor([v]); dist.all_reduce(t, op=dist.ReduceOp.MIN); return int(t.item())
+        enabled = dev.peer_setup(rank, world, ag_bytes, ar_min, dist.barrier)
+    else:
+        os.environ["RAMX_NO_PERSISTENT"] = "1"          # per-column launches + host collective
     dev.load_library(fs.sequence)
     c = fs.cores.copy(); m = new_master(p.L)
     rets = []
     for d in (1, 0):
         rets.append(extend_alignment_sharded(d, c, fs.sequence, m, to_extend_params(p), rank, world, gpu_engine(dev), all_gather))
+    used_persistent = dev.last.persistent
     dev.close()
-    out[rank] = (rets, m.copy(), c.left_len.copy(), c.right_len.copy(), c.score.copy())
+    out[rank] = (rets, m.copy(), c.left_len.copy(), c.right_len.copy(), c.score.copy(), enabled, used_persistent)
     dist.destroy_process_group()
 
 
@@ -72,7 +85,32 @@ def test_two_ranks_one_gpu_equal_single_process_oracle():
     c = fs.cores.copy(); m = new_master(p.L)
     r1 = po.oracle_extend(1, c, fs.sequence, m, p); r0 = po.oracle_extend(0, c, fs.sequence, m, p)
     for rank in range(world):
-        rets, mm, ll, rl, sc = out[rank]
+        rets, mm, ll, rl, sc, enabled, used = out[rank]
+        assert rets == [(r1.ret, r1.rows_executed), (r0.ret, r0.rows_executed)], rank
+        assert np.array_equal(mm, m) and np.array_equal(ll, c.left_len) and np.array_equal(rl, c.right_len)
+        assert np.array_equal(sc, c.score)
+        assert used == 0
+
+
+@pytest.mark.parametrize("W", [14, 40])
+def test_two_ranks_cross_device_persistent_path(W):
+    """Same two ranks, but with the peer mailboxes (hipIpc-mapped fine-grained memory) enabled: each rank runs ONE
+    persistent launch per direction and the per-column vote is exchanged from inside the kernels (system-scope
+    stores into every rank's box).  The two cooperative launches share the test box's single GPU."""
+    from oracle import pyoracle as po
+    from repeatafterme_amd.datamodel import new_master
+    from repeatafterme_amd.synth import synth_family
+    world = 2
+    out = mp.Manager().dict()
+    mp.spawn(_worker, args=(world, _free_port(), out, True, W), nprocs=world, join=True)
+    fs = synth_family(333, 150, W, K=100, seed=12, both_sides=True, minus_frac=0.3, n_run_frac=0.1)
+    p = po.Params.named("14p43g", bandwidth=W, L=150, when_to_stop=25)
+    c = fs.cores.copy(); m = new_master(p.L)
+    r1 = po.oracle_extend(1, c, fs.sequence, m, p); r0 = po.oracle_extend(0, c, fs.sequence, m, p)
+    for rank in range(world):
+        rets, mm, ll, rl, sc, enabled, used = out[rank]
+        assert enabled, "peer self-test failed"
+        assert used == 1, "cross-device persistent launch was not taken (or fell back)"
         assert rets == [(r1.ret, r1.rows_executed), (r0.ret, r0.rows_executed)], rank
         assert np.array_equal(mm, m) and np.array_equal(ll, c.left_len) and np.array_equal(rl, c.right_len)
         assert np.array_equal(sc, c.score)
