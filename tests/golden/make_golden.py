@@ -25,6 +25,8 @@ from oracle import pyoracle as po  # noqa: E402
 from repeatafterme_amd.datamodel import new_master  # noqa: E402
 from repeatafterme_amd.loader import write_ranges, write_twobit  # noqa: E402
 from repeatafterme_amd.synth import synth_adversarial, synth_family  # noqa: E402
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from helpers import make_genome  # noqa: E402
 
 REF = "/root/reference"
 
@@ -49,63 +51,6 @@ CLI_CASES = [
     ("ov_default", "genome_ov", ["-L", "200", "-vvv"]),
     ("ov_w40", "genome_ov", ["-L", "150", "-bandwidth", "40", "-matrix", "14p43g"]),
 ]
-
-
-def make_genome(seed: int):
-    """A few contigs, each with several diverged copies of one family (cores 3-25 bp), both strands,
-    some copies close together / at contig ends, N runs, mixed extendable flags."""
-    rng = np.random.default_rng(1000 + seed)
-    K = 160
-    anc_l = rng.integers(0, 4, K)
-    anc_r = rng.integers(0, 4, K)
-    core = rng.integers(0, 4, int(rng.integers(3, 26)))
-
-    def mutate(a, div=0.12):
-        out = []
-        for b in a:
-            u = rng.random()
-            if u < 0.8 * div:
-                out.append((b + rng.integers(1, 4)) & 3)
-            elif u < 0.9 * div:
-                continue
-            elif u < div:
-                out.extend([int(rng.integers(0, 4)), b])
-            else:
-                out.append(b)
-        return np.array(out, np.int64)
-
-    records, rows = [], []
-    for s in range(int(rng.integers(2, 5))):
-        name = f"ctg{s}" if s else "chrUn_long_contig_name_0"
-        pieces = [rng.integers(0, 4, int(rng.integers(0, 300)))]
-        pos = len(pieces[0])
-        for c in range(int(rng.integers(2, 7))):
-            fl = int(rng.integers(0, K)) if rng.random() < 0.85 else 0
-            fr = int(rng.integers(0, K)) if rng.random() < 0.85 else 0
-            left = mutate(anc_l)[::-1][:fl][::-1] if fl else np.zeros(0, np.int64)
-            right = mutate(anc_r)[:fr]
-            copy = np.concatenate((left, core, right))
-            cs = len(left)
-            minus = rng.random() < 0.4
-            if minus:
-                copy = (3 - copy)[::-1]
-                cs = len(right)
-            if rng.random() < 0.25 and len(copy) > 12:
-                a = int(rng.integers(0, len(copy) - 3))
-                copy = copy.copy()
-                copy[a:a + int(rng.integers(1, 9))] = 99
-                copy[cs:cs + len(core)] = (3 - core)[::-1] if minus else core   # keep the core itself clean
-            pieces.append(copy)
-            rows.append((name, pos + cs, pos + cs + len(core), int(rng.random() < 0.8), int(rng.random() < 0.8),
-                         "-" if minus else "+"))
-            pos += len(copy)
-            gap = rng.integers(0, 4, int(rng.integers(0, 400)) if rng.random() < 0.7 else int(rng.integers(0, 12)))
-            pieces.append(gap)
-            pos += len(gap)
-        records.append((name, np.concatenate(pieces)))
-    order = rng.permutation(len(rows))          # the loader must re-sort
-    rows = [rows[i] for i in order]
-    return records, rows
 
 
 def run_cli(case, stem, argv):
