@@ -195,6 +195,29 @@ int ramx_dev_download(ramx_dev *d, int8_t *cons, int32_t cons_cap, int32_t *trim
  * cell transformed: (m, e) = (max(sub,gap), max(sub+gapopen,gap)+gapextn) -- see csrc/ramx_device.hip. */
 int ramx_dev_peek_state(ramx_dev *d, int32_t flank, int32_t *cells, int32_t *high, int32_t *pos);
 
+/* Batch mode (no counterpart in the reference, whose wrapper util/extend-stk.pl:242-371 starts one
+ * RAMExtend process per family): many families in ONE launch, one workgroup per family, every family with its own
+ * consensus / vote / stop rule.  Flanks are family-major; every family starts at a multiple of 64 in the flank
+ * array (pad with empty flanks: t_lo = 1, t_hi = 0) and has at most 512 flanks; bandwidth 14, 20 or 40 and
+ * non-positive gap penalties (else RAMX_ERR_UNSUPPORTED: run those families one by one through seam 1).
+ * cons is [n_families][L]; trim_* are per (padded) flank; infos per family.  The library must be loaded first. */
+int ramx_dev_run_families(ramx_dev *d, const ramx_flank *flanks, int32_t n_padded, const int32_t *fam_first,
+                          const int32_t *fam_count, int32_t n_families, const ramx_params *p,
+                          ramx_run_info *infos, int8_t *cons, int32_t *trim_high, int32_t *trim_pos);
+
+/* The same on the reference-like flat data model: family f = cores[f] on its own library sequence[f]; master[f] and
+ * the cores' extension lengths / scores are updated exactly as ramx_extend_flat does for one family.  Families the
+ * batch kernel cannot take are run one by one.  Returns 0 or a negative error code; infos[f].ret is the per-family
+ * return value of extend_alignment. */
+typedef struct ramx_family
+{
+  ramx_flat_cores cores;
+  const int8_t *sequence;
+  uint64_t seq_len;
+  int8_t *master;
+} ramx_family;
+int ramx_extend_batch(int direction, ramx_family *families, int32_t n_families, const ramx_params *p, ramx_run_info *infos);
+
 /* multi-GPU: flanks are sharded over ranks; each column's 4 candidate sums are all-reduced
  * (4 x int64, RCCL over xGMI).  unique_id is the 128-byte ncclUniqueId made by rank 0
  * (ramx_comm_unique_id) and handed to the other ranks by the launcher (e.g. torch.distributed). */

@@ -660,13 +660,12 @@ struct PArgs
 // With go <= 0:  m + go + ge <= e <= m + ge  (e = max(sub+go, gap) + ge, m = max(sub, gap)), so d lies in
 // [go + ge, ge] and int16 is exact whenever go + ge >= -32768 (checked on the host).  Each lane owns one dword per
 // cell pair (layout [j/2][thread] dwords, halves by parity of j): conflict-free ds_read_i16 / ds_write_b16.
-template <int W, bool OOB, int BLOCK>
-__device__ __forceinline__ void prk_band(const PArgs &a, const int *s_tab, short *sD, const int r,
+template <int W, bool OOB, int BLOCK, bool INIT = false>
+__device__ __forceinline__ void prk_band(const int go, const int ge, const int *s_tab, short *sD, const int r,
                                          const unsigned (&w)[(2 * W + 1 + 8) / 8 + 2], const int jlo, const int jhi,
                                          int (&M)[2 * W + 1], LaneDP &D)
 {
   constexpr int B = 2 * W + 1;
-  const int go = a.go, ge = a.ge;
   const int edgeF = (r < W) ? go + (r + 1) * ge : SENT;
   const int edgeC = (r + 1 < W) ? go + (r + 2) * ge : SENT;
   const int ph4 = 4 * ((r + 8) & 7);
@@ -690,14 +689,14 @@ __device__ __forceinline__ void prk_band(const PArgs &a, const int *s_tab, short
       int PeNext = NEG;
       if (j + 1 < B) PeNext = M[j + 1] + (int)myD[((j + 1) >> 1) * (2 * BLOCK) + ((j + 1) & 1)];   // previous row's e of cell j+1
       int m, e;
-      band_step<false, true, OOB, false>(go, ge, W, u, t, Pm, PeNext, D, m, e);
+      band_step<INIT, true, OOB, false>(go, ge, W, u, t, Pm, PeNext, D, m, e);
       M[j] = m;
       myD[(j >> 1) * (2 * BLOCK) + (j & 1)] = (short)(e - m);
     }
     else
     {
       int dm, de;
-      band_step<false, false, OOB, false>(go, ge, W, u, t, 0, 0, D, dm, de);
+      band_step<INIT, false, OOB, false>(go, ge, W, u, t, 0, 0, D, dm, de);
     }
   }
 }
@@ -881,8 +880,8 @@ __global__ __launch_bounds__(BLOCK, 2) void ramx_persistent_kernel(const PArgs a
 #pragma unroll
       for (int c = 0; c < 4; c++) { D.eA[c] = NEG; D.bestA[c] = NEG; }
       const bool all_in = __all((jlo <= 0) && (jhi >= B));
-      if (all_in) prk_band<W, false, BLOCK>(a, s_tab, sD, r, w, jlo, jhi, M, D);
-      else prk_band<W, true, BLOCK>(a, s_tab, sD, r, w, jlo, jhi, M, D);
+      if (all_in) prk_band<W, false, BLOCK>(a.go, a.ge, s_tab, sD, r, w, jlo, jhi, M, D);
+      else prk_band<W, true, BLOCK>(a.go, a.ge, s_tab, sD, r, w, jlo, jhi, M, D);
       if (D.bestF > high) { high = D.bestF; pos = r + D.jbest - W; }   // ram_extend.c:1140-1150
       if (new_max) { thigh = high; tpos = pos; }                        // :1203-1207
       if (n < a.Nx)
@@ -932,6 +931,143 @@ __global__ __launch_bounds__(BLOCK, 2) void ramx_persistent_kernel(const PArgs a
     o.max_ext = max_ext; o.max_row = max_row; o.stopped = stopped; o.rows_done = rows_done; o.overflow = ovf; o.besta = 0;
     o.pad = failed;
     *a.ctl_out = o;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// batch mode: one BLOCK = one family
+// ------------------------------------------------------------------------------------------
+//
+// Real inputs are hundreds of families of ~100 flanks each (util/extend-stk.pl runs one RAMExtend process per
+// family).  A family of up to BLOCK flanks fits one workgroup, so its per-column vote is a block-local LDS
+// reduction: no device-wide barrier, no atomics, no cooperative launch, any number of families per launch (blocks
+// that are not resident simply wait their turn), each family stopping on its own fit-preferred rule.  Rows live in
+// registers / LDS exactly as in the persistent kernel; the boundary row and the candidates of row 0 are produced
+// in-kernel (column "-1").
+
+struct FamDesc { int tile0, ntiles, nx, pad; };     // first 64-flank tile, tiles, flanks of the family
+
+struct FArgs
+{
+  const unsigned *bases;
+  const int2 *bounds;
+  const FamDesc *fam;
+  int2 *trim;                   // per flank
+  RamxCtl *ctl_out;             // per family
+  signed char *cons_out;        // [family][L]
+  int Np, L, go, ge, cap, minimp, when_to_stop;
+  int tab[RAMX_NCLASS][4];
+};
+
+template <int W, int BLOCK>
+__global__ __launch_bounds__(BLOCK, 2) void ramx_family_kernel(const FArgs a)
+{
+  constexpr int B = 2 * W + 1, NW = (B + 8) / 8 + 2, WPB = BLOCK / 64, RS = 2 * BLOCK;
+  __shared__ __attribute__((aligned(16))) int s_tab4[4][TAB_ROWS * TAB_STRIDE];
+  __shared__ long long s_red[2][WPB][4];
+  __shared__ short sD[((B + 1) / 2) * RS];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const FamDesc fd = a.fam[blockIdx.x];
+  const bool live = wave < fd.ntiles;
+  const int n = (fd.tile0 + (live ? wave : 0)) * 64 + lane;
+  const bool active = live && (wave * 64 + lane) < fd.nx;
+
+  for (int i = threadIdx.x; i < 4 * TAB_ROWS * TAB_STRIDE; i += BLOCK)
+  {
+    const int bt = i / (TAB_ROWS * TAB_STRIDE), e = i % (TAB_ROWS * TAB_STRIDE), row = e / TAB_STRIDE, col = e % TAB_STRIDE;
+    int v = 0;
+    if (row < RAMX_NCLASS) v = (col < 4) ? a.tab[row][col] : (col == 4 ? a.tab[row][bt] : 0);
+    s_tab4[bt][e] = v;
+  }
+  __syncthreads();
+
+  int M[B];
+#pragma unroll
+  for (int j = 0; j < B; j++) M[j] = 0;
+  int high = 0, pos = 0, thigh = 0, tpos = 0;
+  const int2 bd = a.bounds[n];
+  long long max_ext = 0;
+  int max_row = -1, rows_done = 0, ovf = 0, stopped = 0;
+
+  for (int r = -1; r < a.L; r++)
+  {
+    unsigned w[NW];
+    {
+      const unsigned *bp = a.bases + (size_t)((r + 8) >> 3) * a.Np + n;
+#pragma unroll
+      for (int k = 0; k < NW; k++) w[k] = bp[(size_t)k * a.Np];
+    }
+    int besta = 0;
+    bool new_max = false;
+    if (r >= 0)
+    {
+      // vote of row r: block-local (written at the end of the previous iteration, double buffered)
+      long long curr = 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+      {
+        long long vk = 0;
+#pragma unroll
+        for (int wv = 0; wv < WPB; wv++) vk += s_red[r & 1][wv][k];
+        if (vk > 2147483647LL || vk < -2147483648LL) ovf = 1;
+        if (vk > curr) { curr = vk; besta = k; }
+      }
+      int dist = max_row - r;
+      dist = dist < 0 ? -dist : dist;
+      new_max = curr >= max_ext + (long long)dist * a.minimp;
+      if (new_max) { max_row = r; max_ext = curr; }
+      int d2 = r - max_row;
+      d2 = d2 < 0 ? -d2 : d2;
+      stopped = d2 >= a.when_to_stop;
+      rows_done = r + 1;
+      if (threadIdx.x == 0) a.cons_out[(size_t)blockIdx.x * a.L + r] = (signed char)besta;
+    }
+    const int *s_tab = s_tab4[besta];
+    long long contrib[4] = { 0, 0, 0, 0 };
+    if (live)
+    {
+      const int jlo = bd.x - r, jhi = bd.y - r;
+      LaneDP D;
+      D.eC = NEG; D.mPrev = NEG - 1000000; D.bestF = NEG; D.jbest = 0;
+#pragma unroll
+      for (int c = 0; c < 4; c++) { D.eA[c] = NEG; D.bestA[c] = NEG; }
+      if (r < 0)
+        prk_band<W, true, BLOCK, true>(a.go, a.ge, s_tab, sD, r, w, jlo, jhi, M, D);
+      else
+      {
+        const bool all_in = __all((jlo <= 0) && (jhi >= B));
+        if (all_in) prk_band<W, false, BLOCK>(a.go, a.ge, s_tab, sD, r, w, jlo, jhi, M, D);
+        else prk_band<W, true, BLOCK>(a.go, a.ge, s_tab, sD, r, w, jlo, jhi, M, D);
+        if (D.bestF > high) { high = D.bestF; pos = r + D.jbest - W; }
+        if (new_max) { thigh = high; tpos = pos; }
+      }
+      if (active)
+      {
+        const int capv = high + a.cap;
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+        {
+          const int b = D.bestA[c] < 0 ? 0 : D.bestA[c];
+          contrib[c] = (b >= capv) ? b : capv;
+        }
+      }
+    }
+    if (stopped || r == a.L - 1) break;
+#pragma unroll
+    for (int c = 0; c < 4; c++) contrib[c] = wave_sum_ll(contrib[c]);
+    if (lane == 0)
+    {
+#pragma unroll
+      for (int c = 0; c < 4; c++) s_red[(r + 1) & 1][wave][c] = contrib[c];
+    }
+    __syncthreads();
+  }
+  if (live) a.trim[n] = make_int2(thigh, tpos);
+  if (threadIdx.x == 0)
+  {
+    RamxCtl o;
+    o.max_ext = max_ext; o.max_row = max_row; o.stopped = stopped; o.rows_done = rows_done; o.overflow = ovf; o.besta = 0; o.pad = 0;
+    a.ctl_out[blockIdx.x] = o;
   }
 }
 
@@ -1321,6 +1457,106 @@ static int prk_run(ramx_dev *d, const KArgs &a, int L, bool *used)
   if (block == 256)
     return (W == 14) ? prk_launch<14, 256>(d, pa, blocks) : (W == 20) ? prk_launch<20, 256>(d, pa, blocks) : prk_launch<40, 256>(d, pa, blocks);
   return (W == 14) ? prk_launch<14, 512>(d, pa, blocks) : (W == 20) ? prk_launch<20, 512>(d, pa, blocks) : prk_launch<40, 512>(d, pa, blocks);
+}
+
+// ---- batch mode -------------------------------------------------------------------------------
+template <int W, int BLOCK>
+static int fam_launch(ramx_dev *d, const FArgs &fa, int F)
+{
+  hipLaunchKernelGGL((ramx_family_kernel<W, BLOCK>), dim3(F), dim3(BLOCK), 0, d->stream, fa);
+  HIPCHK(hipGetLastError());
+  return RAMX_OK;
+}
+
+extern "C" int ramx_dev_run_families(ramx_dev *d, const ramx_flank *flanks, int32_t n_padded, const int32_t *fam_first,
+                                     const int32_t *fam_count, int32_t n_families, const ramx_params *p,
+                                     ramx_run_info *infos, int8_t *cons, int32_t *trim_high, int32_t *trim_pos)
+{
+  if (!d || !p || !p->matrix || n_families < 0 || n_padded < 0 || (n_padded & 63) || (n_families && (!fam_first || !fam_count || !flanks)))
+  { ramx_set_error("ramx_dev_run_families: bad argument"); return RAMX_ERR_ARG; }
+  HIPCHK(hipSetDevice(d->ordinal));
+  const int W = p->bandwidth, L = p->L;
+  if (!prk_has_width(W) || p->gapopen > 0 || p->gapextn > 0 || p->gapopen + p->gapextn < -32768 || L < 0)
+  { ramx_set_error("batch mode needs bandwidth 14/20/40 and non-positive gap penalties"); return RAMX_ERR_UNSUPPORTED; }
+  int maxn = 0;
+  for (int f = 0; f < n_families; f++)
+  {
+    if (fam_count[f] < 0 || (fam_first[f] & 63) || fam_first[f] + fam_count[f] > n_padded) { ramx_set_error("ramx_dev_run_families: bad family layout"); return RAMX_ERR_ARG; }
+    if (fam_count[f] > maxn) maxn = fam_count[f];
+  }
+  if (maxn > 512) { ramx_set_error("batch mode: a family has more than 512 flanks"); return RAMX_ERR_UNSUPPORTED; }
+  if (n_families == 0) return RAMX_OK;
+  const int Np = n_padded > 0 ? n_padded : 64;
+  const int KW = (L + 2 * W + 2) / 8 + 8;
+  int rc;
+  if ((rc = ensure(&d->d_flanks, &d->cap_flanks, (size_t)Np * sizeof(ramx_flank)))) return rc;
+  if ((rc = ensure(&d->d_bases, &d->cap_bases, (size_t)KW * Np * sizeof(unsigned)))) return rc;
+  if (d->d_bounds) { HIPCHK(hipFree(d->d_bounds)); d->d_bounds = NULL; }
+  if (d->d_trim) { HIPCHK(hipFree(d->d_trim)); d->d_trim = NULL; }
+  HIPCHK(hipMalloc((void **)&d->d_bounds, (size_t)Np * sizeof(int2)));
+  HIPCHK(hipMalloc((void **)&d->d_trim, (size_t)Np * sizeof(int2)));
+  if ((rc = ensure(&d->d_cons, &d->cap_cons, (size_t)n_families * (L > 0 ? L : 1) + 16))) return rc;
+  FamDesc *hfd = (FamDesc *)malloc(sizeof(FamDesc) * n_families);
+  for (int f = 0; f < n_families; f++)
+  {
+    hfd[f].tile0 = fam_first[f] / 64; hfd[f].ntiles = (fam_count[f] + 63) / 64; hfd[f].nx = fam_count[f]; hfd[f].pad = 0;
+    if (hfd[f].ntiles == 0) hfd[f].ntiles = 0;
+  }
+  FamDesc *dfd = NULL; RamxCtl *dctl = NULL;
+  HIPCHK(hipMalloc((void **)&dfd, sizeof(FamDesc) * n_families));
+  HIPCHK(hipMalloc((void **)&dctl, sizeof(RamxCtl) * n_families));
+  HIPCHK(hipMemcpyAsync(dfd, hfd, sizeof(FamDesc) * n_families, hipMemcpyHostToDevice, d->stream));
+  if (n_padded) HIPCHK(hipMemcpyAsync(d->d_flanks, flanks, (size_t)n_padded * sizeof(ramx_flank), hipMemcpyHostToDevice, d->stream));
+  dim3 grid((Np + 255) / 256, KW);
+  hipLaunchKernelGGL(ramx_pack_kernel, grid, dim3(256), 0, d->stream, d->d_lib, (unsigned long long)d->lib_len, d->d_flanks,
+                     n_padded, Np, W, d->d_bases, d->d_bounds);
+  HIPCHK(hipGetLastError());
+  FArgs fa;
+  memset(&fa, 0, sizeof(fa));
+  fa.bases = d->d_bases; fa.bounds = d->d_bounds; fa.fam = dfd; fa.trim = d->d_trim; fa.ctl_out = dctl; fa.cons_out = d->d_cons;
+  fa.Np = Np; fa.L = L; fa.go = p->gapopen; fa.ge = p->gapextn; fa.cap = p->cappenalty; fa.minimp = p->minimprovement;
+  fa.when_to_stop = p->when_to_stop;
+  for (int c = 0; c < RAMX_NCLASS; c++)
+  {
+    const int code = (c == 8) ? RAMX_SYM_N : c;
+    for (int k = 0; k < 4; k++) fa.tab[c][k] = p->matrix[k * 100 + code];
+  }
+  HIPCHK(hipEventRecord(d->ev_begin, d->stream));
+  if (maxn <= 256)
+    rc = (W == 14) ? fam_launch<14, 256>(d, fa, n_families) : (W == 20) ? fam_launch<20, 256>(d, fa, n_families) : fam_launch<40, 256>(d, fa, n_families);
+  else
+    rc = (W == 14) ? fam_launch<14, 512>(d, fa, n_families) : (W == 20) ? fam_launch<20, 512>(d, fa, n_families) : fam_launch<40, 512>(d, fa, n_families);
+  if (rc != RAMX_OK) { free(hfd); return rc; }
+  HIPCHK(hipEventRecord(d->ev_end, d->stream));
+  HIPCHK(hipStreamSynchronize(d->stream));
+  float ms = 0;
+  HIPCHK(hipEventElapsedTime(&ms, d->ev_begin, d->ev_end));
+  RamxCtl *hctl = (RamxCtl *)malloc(sizeof(RamxCtl) * n_families);
+  HIPCHK(hipMemcpy(hctl, dctl, sizeof(RamxCtl) * n_families, hipMemcpyDeviceToHost));
+  if (cons && L > 0) HIPCHK(hipMemcpy(cons, d->d_cons, (size_t)n_families * L, hipMemcpyDeviceToHost));
+  if ((trim_high || trim_pos) && n_padded)
+  {
+    int2 *tmp = (int2 *)malloc((size_t)n_padded * sizeof(int2));
+    HIPCHK(hipMemcpy(tmp, d->d_trim, (size_t)n_padded * sizeof(int2), hipMemcpyDeviceToHost));
+    for (int i = 0; i < n_padded; i++) { if (trim_high) trim_high[i] = tmp[i].x; if (trim_pos) trim_pos[i] = tmp[i].y; }
+    free(tmp);
+  }
+  for (int f = 0; f < n_families && infos; f++)
+  {
+    memset(&infos[f], 0, sizeof(ramx_run_info));
+    infos[f].ret = hctl[f].max_row + 1;
+    infos[f].rows_executed = hctl[f].rows_done;
+    infos[f].limit_warning = (hctl[f].stopped && hctl[f].rows_done - 1 == L - 1) ? 1 : 0;
+    infos[f].overflow32 = hctl[f].overflow;
+    infos[f].n_extendable = fam_count[f];
+    infos[f].launches = 1;
+    infos[f].loop_ms = ms;
+    infos[f].persistent = 1;
+  }
+  free(hctl); free(hfd);
+  (void)hipFree(dfd); (void)hipFree(dctl);
+  d->ready = 0;       // the single-family buffers were reused: begin_direction must be called again before run_direction
+  return RAMX_OK;
 }
 
 extern "C" int ramx_dev_run_direction(ramx_dev *d, ramx_run_info *info)

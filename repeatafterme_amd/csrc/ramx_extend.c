@@ -241,6 +241,104 @@ int ramx_extend_alignment(int direction, struct coreAlignment *coreAlign, int **
   return ret;
 }
 
+
+/*
+ * Batch mode: many families, one launch (include/ramx.h).  Libraries are concatenated into one device buffer,
+ * every family's flanks are padded to a multiple of 64 with empty flanks, results are written back per family
+ * exactly as ramx_extend_flat does (ram_extend.c:1092-1095, 1234-1247).
+ */
+int ramx_extend_batch(int direction, ramx_family *fam, int32_t F, const ramx_params *p, ramx_run_info *infos)
+{
+  if (F < 0 || (F && !fam) || !p) { ramx_set_error("ramx_extend_batch: bad argument"); return RAMX_ERR_ARG; }
+  ramx_run_info *own = NULL;
+  if (!infos) infos = own = (ramx_run_info *)calloc((size_t)(F ? F : 1), sizeof(ramx_run_info));
+  ramx_dev *d = ramx_default_device();
+  if (!d) { free(own); return RAMX_ERR_NO_DEVICE; }
+  const int W = p->bandwidth, L = p->L;
+  int rc = RAMX_OK;
+  /* which families can the batch kernel take? */
+  int batchable = (W == 14 || W == 20 || W == 40) && p->gapopen <= 0 && p->gapextn <= 0 && p->gapopen + p->gapextn >= -32768;
+  uint64_t total_len = 0;
+  size_t total_pad = 0;
+  int *take = (int *)calloc((size_t)(F ? F : 1), sizeof(int));
+  for (int f = 0; f < F; f++)
+  {
+    int nx = 0;
+    for (int n = 0; n < fam[f].cores.n; n++)
+      if ((direction && fam[f].cores.right_ext[n]) || (!direction && fam[f].cores.left_ext[n])) nx++;
+    take[f] = batchable && nx <= 512;
+    if (take[f]) { total_len += fam[f].seq_len; total_pad += (size_t)((nx + 63) / 64) * 64; }
+  }
+  int8_t *lib = (int8_t *)malloc(total_len ? total_len : 1);
+  ramx_flank *fl = (ramx_flank *)malloc(sizeof(ramx_flank) * (total_pad ? total_pad : 1));
+  int32_t *map = (int32_t *)malloc(sizeof(int32_t) * (total_pad ? total_pad : 1));
+  int32_t *first = (int32_t *)malloc(sizeof(int32_t) * (size_t)(F ? F : 1));
+  int32_t *count = (int32_t *)malloc(sizeof(int32_t) * (size_t)(F ? F : 1));
+  int32_t *fidx = (int32_t *)malloc(sizeof(int32_t) * (size_t)(F ? F : 1));
+  uint64_t at = 0;
+  size_t fpos = 0;
+  int nb = 0;
+  for (int f = 0; f < F; f++)
+  {
+    if (!take[f]) continue;
+    if (fam[f].seq_len) memcpy(lib + at, fam[f].sequence, fam[f].seq_len);
+    ramx_flank *tmp = (ramx_flank *)malloc(sizeof(ramx_flank) * (size_t)(fam[f].cores.n > 0 ? fam[f].cores.n : 1));
+    int32_t *tmap = (int32_t *)malloc(sizeof(int32_t) * (size_t)(fam[f].cores.n > 0 ? fam[f].cores.n : 1));
+    const int nx = ramx_resolve_flanks(direction, &fam[f].cores, W, L, tmp, tmap);
+    first[nb] = (int32_t)fpos; count[nb] = nx; fidx[nb] = f;
+    for (int i = 0; i < nx; i++) { fl[fpos] = tmp[i]; fl[fpos].start += (int64_t)at; map[fpos] = tmap[i]; fpos++; }
+    while (fpos & 63) { memset(&fl[fpos], 0, sizeof(ramx_flank)); fl[fpos].t_lo = 1; fl[fpos].t_hi = 0; fl[fpos].step = 1; map[fpos] = -1; fpos++; }
+    free(tmp); free(tmap);
+    at += fam[f].seq_len;
+    nb++;
+  }
+  if (nb > 0)
+  {
+    ramx_run_info *binfo = (ramx_run_info *)calloc((size_t)nb, sizeof(ramx_run_info));
+    int8_t *cons = (int8_t *)malloc((size_t)nb * (size_t)(L > 0 ? L : 1));
+    int32_t *th = (int32_t *)malloc(sizeof(int32_t) * (fpos ? fpos : 1));
+    int32_t *tp = (int32_t *)malloc(sizeof(int32_t) * (fpos ? fpos : 1));
+    g_lib_ptr = NULL; g_lib_len = 0;                 /* the cached single-family library is replaced */
+    rc = ramx_dev_load_library(d, lib, at);
+    if (rc == RAMX_OK) rc = ramx_dev_run_families(d, fl, (int32_t)fpos, first, count, nb, p, binfo, cons, th, tp);
+    if (rc == RAMX_OK)
+    {
+      for (int b = 0; b < nb; b++)
+      {
+        const int f = fidx[b];
+        ramx_flat_cores *c = &fam[f].cores;
+        infos[f] = binfo[b];
+        for (int r = 0; r < binfo[b].rows_executed; r++)
+        {
+          if (direction) fam[f].master[(size_t)L + p->l + r] = cons[(size_t)b * L + r];
+          else fam[f].master[(size_t)L - r - 1] = cons[(size_t)b * L + r];
+        }
+        for (int i = 0; i < count[b]; i++)
+        {
+          const size_t g = (size_t)first[b] + i;
+          if (th[g] > 0 && tp[g] >= 0)
+          {
+            const int n = map[g];
+            if (direction) c->right_len[n] = tp[g] + 1;
+            else c->left_len[n] = tp[g] + 1;
+            c->score[n] += th[g];
+          }
+        }
+      }
+    }
+    free(binfo); free(cons); free(th); free(tp);
+  }
+  /* families the batch kernel cannot take (other band widths, positive penalties, > 512 flanks): one by one */
+  for (int f = 0; f < F && rc == RAMX_OK; f++)
+  {
+    if (take[f]) continue;
+    int r1 = ramx_extend_flat(direction, &fam[f].cores, fam[f].sequence, fam[f].seq_len, fam[f].master, p, &infos[f]);
+    if (r1 < 0) rc = r1;
+  }
+  free(lib); free(fl); free(map); free(first); free(count); free(fidx); free(take); free(own);
+  return rc;
+}
+
 /* bnw_extend.c:87-155 -- kept for link compatibility; the device path never reads it, so a single
  * zeroed block with the same index shape is enough (and avoids 2*N*B mallocs). */
 int ****ramx_allocate_score(int num_align, int bandwidth)

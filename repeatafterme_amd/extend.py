@@ -58,3 +58,25 @@ def extend_alignment(direction: int, cores: CoreSet, sequence: np.ndarray, maste
                             master.ctypes.data, C.byref(cp), C.byref(ci))
     _lib.check(rc, "ramx_extend_flat")
     return _info(ci)
+
+
+def extend_batch(direction: int, families, p: ExtendParams):
+    """Many families in one launch (C-ABI ramx_extend_batch).  `families` is a list of (cores, sequence, master);
+    every family is updated in place exactly like extend_alignment does for one.  Returns one RunInfo per family."""
+    L = _lib.lib()
+    n = len(families)
+    arr = (_lib.Family * max(n, 1))()
+    keep = []
+    for i, (cores, sequence, master) in enumerate(families):
+        assert sequence.dtype == np.int8 and sequence.flags.c_contiguous and master.dtype == np.int8
+        arr[i].cores = _lib.FlatCores(cores.n, *[getattr(cores, k).ctypes.data for k in
+                                                 ("left_pos", "right_pos", "lower", "upper", "orient", "left_ext",
+                                                  "right_ext", "left_len", "right_len", "score")])
+        arr[i].sequence = sequence.ctypes.data
+        arr[i].seq_len = len(sequence)
+        arr[i].master = master.ctypes.data
+        keep.append((cores, sequence, master))
+    cp, _keep = _params(p)
+    infos = (_lib.RunInfo * max(n, 1))()
+    _lib.check(L.ramx_extend_batch(int(direction), arr, n, C.byref(cp), infos), "ramx_extend_batch")
+    return [_info(infos[i]) for i in range(n)]
