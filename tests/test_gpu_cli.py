@@ -105,3 +105,29 @@ def test_extend_alignment_struct_entry():
     assert [a.rightExtensionLen for a in arr] == c2.right_len.tolist()
     assert [a.leftExtensionLen for a in arr] == c2.left_len.tolist()
     assert [a.score for a in arr] == c2.score.tolist()
+
+
+SEAM1 = os.path.join(ROOT, "oracle", "_ref", "RAMExtend_seam1")
+
+
+@pytest.mark.skipif(not os.path.exists(SEAM1), reason="oracle/_ref/RAMExtend_seam1 not built (needs /root/reference at build time)")
+@pytest.mark.parametrize("case", CASES)
+def test_reference_main_with_only_the_loop_replaced(case, tmp_path):
+    """INTEGRATION.md section B, for real: the reference's own main(), loader, report and writers, linked against
+    libramx with extend_alignment() replaced by the seam-1 binding (oracle/seam1_shim.c).  Its output must be
+    byte-identical to the unmodified reference's, version line included."""
+    argv = open(os.path.join(G, "cli", case, "argv")).read().split()
+    stem = STEM[case.split("_")[0]]
+    cmd = [SEAM1, "-twobit", f"inputs/{stem}.2bit", "-ranges", f"inputs/{stem}.tsv", "-cons", str(tmp_path / "cons"),
+           "-outtsv", str(tmp_path / "tsv"), "-outfa", str(tmp_path / "fa")] + argv
+    r = subprocess.run(cmd, cwd=G, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got = r.stdout.replace(str(tmp_path) + "/", "").splitlines()
+    want = open(os.path.join(G, "cli", case, "stdout")).read().splitlines()
+    got = [l for l in got if not l.startswith("Program duration is")]
+    want = [l for l in want if not l.startswith("Program duration is")]
+    assert got == want
+    for f in ("cons", "tsv", "fa"):
+        ref_f = os.path.join(G, "cli", case, f)
+        if os.path.exists(ref_f):
+            assert open(tmp_path / f).read() == open(ref_f).read(), f
