@@ -4,9 +4,11 @@
  * defaults), same stdout / -cons / -outtsv / -outfa bytes; the two extend_alignment calls go to
  * the device path (ramx_extend_alignment).
  */
+#include <fcntl.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#include <unistd.h>
 
 #include "ramx_internal.h"
 
@@ -157,133 +159,57 @@ static void write_wrapped(FILE *fp, const char *master, uint64_t from, uint64_t 
   if ((x - masterstart) % 80 > 0) fputc('\n', fp);
 }
 
-int ramx_cli_main(int argc, char **argv)
+
+/* everything the command line decides */
+struct cli_opts
 {
-  const time_t t_start = time(0);
-  const char *ranges_file = NULL, *outtsv = NULL, *outfa = NULL, *outmat = NULL, *cons_file = NULL;
-  const char *seq_file = NULL, *matrix_name = NULL;
-  int flanking = 0, L, bandwidth, maxn, when_to_stop, num_threads = 0, verbose;
-  int gap_ext = 0, gap_open = 0, match = 0, mismatch = 0, cappenalty = 0, minimprovement = 0;
-  const int l = 1;
+  const char *ranges_file, *outtsv, *outfa, *outmat, *cons_file, *seq_file, *matrix_name, *batch_file;
+  int flanking, L, bandwidth, maxn, when_to_stop, num_threads, verbose;
+  int gap_ext, gap_open, match, mismatch, cappenalty, minimprovement, is_rs;
   struct scoringSystem *sp;
+};
 
-  if (opt_bool(argc, argv, "-version"))
-  {
-    printf("RAMExtend Version %s - build %s date %s\n", k_version, k_build, k_build_date);
-    exit(0);
-  }
-  if (!opt_string(argc, argv, "-ranges", &ranges_file)) usage();
-
-  opt_int(argc, argv, "-addflanking", &flanking);
-  opt_string(argc, argv, "-outtsv", &outtsv);
-  opt_string(argc, argv, "-outfa", &outfa);
-  opt_string(argc, argv, "-outmat", &outmat);
-  opt_string(argc, argv, "-cons", &cons_file);
-  if (!opt_int(argc, argv, "-L", &L)) L = 10000;
-  if (!opt_int(argc, argv, "-bandwidth", &bandwidth)) bandwidth = 14;
-  if (!opt_int(argc, argv, "-maxoccurrences", &maxn)) maxn = 10000;
-  if (!opt_int(argc, argv, "-stopafter", &when_to_stop)) when_to_stop = 100;
-  if (!opt_int(argc, argv, "-threads", &num_threads)) num_threads = 0;
-  verbose = opt_bool(argc, argv, "-vvvvvv") ? 20 : opt_bool(argc, argv, "-vvvvv") ? 12 :
-            opt_bool(argc, argv, "-vvvv") ? 10 : opt_bool(argc, argv, "-vvv") ? 3 :
-            opt_bool(argc, argv, "-vv") ? 2 : opt_bool(argc, argv, "-v") ? 1 : 0;
-
-  if (!opt_string(argc, argv, "-matrix", &matrix_name)) matrix_name = "20p43g";
-  if (matrix_name == NULL) matrix_name = "";
-  const int is_rs = strcmp(matrix_name, "repeatscout") == 0;
-  if (is_rs)
-  {
-    if (opt_int(argc, argv, "-match", &match) && opt_int(argc, argv, "-mismatch", &mismatch) &&
-        opt_int(argc, argv, "-gap", &gap_ext))
-      sp = ramx_get_repeatscout_matrix(match, mismatch, gap_ext);
-    else
-      sp = ramx_get_repeatscout_matrix(1, -1, -5);
-  }
-  else
-  {
-    if (opt_int(argc, argv, "-gapopen", &gap_open) && opt_int(argc, argv, "-gapext", &gap_ext))
-      sp = ramx_get_matrix_using_gap_penalties(matrix_name, gap_open, gap_ext);
-    else
-      sp = ramx_get_matrix(matrix_name);
-  }
-  /* per-matrix defaults, ram_extend.c:301-344 */
-  {
-    int def_min, def_cap;
-    if (!strcmp(matrix_name, "14p43g") || !strcmp(matrix_name, "18p43g") || !strcmp(matrix_name, "20p43g")) { def_min = 27; def_cap = -90; }
-    else if (!strcmp(matrix_name, "25p43g")) { def_min = 24; def_cap = -90; }
-    else if (is_rs) { def_min = 3; def_cap = -20; }
-    else { printf("Matrix name not found!\n"); exit(1); }
-    if (!opt_int(argc, argv, "-minimprovement", &minimprovement)) minimprovement = def_min;
-    if (!opt_int(argc, argv, "-cappenalty", &cappenalty)) cappenalty = def_cap;
-  }
-
-  char *master = (char *)malloc((size_t)(2 * (long)L + l + 1));
-  if (!master) { fprintf(stderr, "Could not allocate space for master array\n"); exit(1); }
-  memset(master, 0, (size_t)(2 * (long)L + l + 1));
-
-  struct coreAlignment *cores = NULL;
-  struct sequenceLibrary *lib = NULL;
-  int N = 0;
-  if (opt_string(argc, argv, "-twobit", &seq_file))
-    lib = ramx_load_sequence_subset_minimal(seq_file, ranges_file, &cores, &N, L + bandwidth);
-  else if (opt_string(argc, argv, "-sequence", &seq_file))
-  {
-    printf("-sequence is deprecated!....may return someday\n");
-    exit(1);
-  }
-  else
-    usage();
-
-  if (outmat != NULL)
-  {
-    fprintf(stderr, "RAMExtend(ramx): -outmat (per-cell DP path dump) is not available on the device path\n");
-    exit(1);
-  }
-
-  /* banner + parameters, ram_extend.c:397-400, 793-826 */
+/* banner + parameters, ram_extend.c:397-400, 793-826 */
+static void print_header(const struct cli_opts *o, const char *ranges_file, int N, const struct sequenceLibrary *lib)
+{
   printf("\nRAMExtend Version %s - build %s date %s\n", k_version, k_build, k_build_date);
   printf("--------------------------------------------------------------\n");
   printf("Parameters:\n");
-  printf("  VERBOSE %d\n", verbose);
-  printf("  SEQUENCE_FILE %s\n", seq_file);
+  printf("  VERBOSE %d\n", o->verbose);
+  printf("  SEQUENCE_FILE %s\n", o->seq_file);
   printf("  RANGES_FILE %s\n", ranges_file);
-  if (num_threads)
-    printf("  Multi-Threaded-Masking (EXPERIMENTAL): num_threads = %d\n", num_threads);
-  printf("  L %d\n", L);
-  printf("  BANDWIDTH (bandwidth) %d\n", bandwidth);
-  printf("  MAXN %d\n", maxn);
-  if (is_rs)
+  if (o->num_threads)
+    printf("  Multi-Threaded-Masking (EXPERIMENTAL): num_threads = %d\n", o->num_threads);
+  printf("  L %d\n", o->L);
+  printf("  BANDWIDTH (bandwidth) %d\n", o->bandwidth);
+  printf("  MAXN %d\n", o->maxn);
+  if (o->is_rs)
   {
     printf("  SCORING SYSTEM: Original RepeatScout method\n");
-    printf("     - GAP = %d\n", sp->gapextn);
-    printf("     - MATCH = %d\n", match);
-    printf("     - MISMATCH = %d\n", mismatch);
+    printf("     - GAP = %d\n", o->sp->gapextn);
+    printf("     - MATCH = %d\n", o->match);
+    printf("     - MISMATCH = %d\n", o->mismatch);
   }
   else
   {
-    printf("  SCORING SYSTEM: Internally coded matrix '%s'\n", matrix_name);
-    printf("     - GAP_OPEN = %d\n", sp->gapopen);
-    printf("     - GAP_EXT = %d\n", sp->gapextn);
+    printf("  SCORING SYSTEM: Internally coded matrix '%s'\n", o->matrix_name);
+    printf("     - GAP_OPEN = %d\n", o->sp->gapopen);
+    printf("     - GAP_EXT = %d\n", o->sp->gapextn);
   }
-  printf("     - CAPPENALTY %d\n", cappenalty);
-  printf("     - MINIMPROVEMENT %d\n", minimprovement);
-  printf("  WHEN_TO_STOP %d\n", when_to_stop);
+  printf("     - CAPPENALTY %d\n", o->cappenalty);
+  printf("     - MINIMPROVEMENT %d\n", o->minimprovement);
+  printf("  WHEN_TO_STOP %d\n", o->when_to_stop);
   printf("--------------------------------------------------------------\n");
   printf("Read in %d ranges, and %ld bp of sequence\n\n", N, (long)lib->length);
+}
 
-  ramx_print_core_edges(cores, lib, 0, verbose ? 1 : 0);
-  master[L] = RAMX_SYM_N;   /* the l = 1 spacer, never printed (ram_extend.c:415-416) */
-
-  ramx_set_runtime(verbose, when_to_stop, l);
-  fflush(stdout);
-  int rightbp = ramx_extend_alignment(1, cores, NULL, lib, master, bandwidth, cappenalty, minimprovement, L, N, sp, NULL);
-  printf("Extended right: %d bp\n", rightbp);
-  ramx_overlap_avoidance(cores, lib);
+/* consensus records, report table, -cons / -outtsv / -outfa: reference ram_extend.c:515-781 */
+static void write_results(const struct cli_opts *o, struct coreAlignment *cores, struct sequenceLibrary *lib, const char *master,
+                          int rightbp, int leftbp, const char *cons_file, const char *outtsv, const char *outfa)
+{
+  const int L = o->L, l = 1, flanking = o->flanking;
   const long masterend = (long)L + l + rightbp;
-  int leftbp = ramx_extend_alignment(0, cores, NULL, lib, master, bandwidth, cappenalty, minimprovement, L, N, sp, NULL);
-  printf("Extended left : %d bp\n", leftbp);
   const long masterstart = (long)L - leftbp;
-
   if (rightbp > 0 || leftbp > 0)
   {
     FILE *fp = NULL, *fp_fa = NULL;
@@ -410,9 +336,286 @@ int ramx_cli_main(int argc, char **argv)
     if (fp_fa != NULL) fclose(fp_fa);
   }
 
+}
+
+
+/*
+ * -batch <list>: many families in one process and ONE launch per direction (no counterpart in the reference, whose
+ * wrapper util/extend-stk.pl:242-371 starts one RAMExtend per family).  Every non-empty, non-# line of <list> is
+ *     ranges.tsv <TAB> log <TAB> cons.fa <TAB> out.tsv <TAB> out.fa          ("-" = not wanted)
+ * All other options (-twobit, -L, -bandwidth, -matrix ...) are shared.  For every family the log file receives
+ * exactly what a stand-alone run prints on stdout, and the three output files are what -cons/-outtsv/-outfa give.
+ */
+struct batch_item
+{
+  char *ranges, *log, *cons, *tsv, *fa;
+  struct coreAlignment *cores;
+  struct sequenceLibrary *lib;
+  int N, rightbp, leftbp;
+  char *master;
+};
+
+static void to_log(const char *path, int truncate)
+{
+  fflush(stdout);
+  int fd = open(path, O_WRONLY | O_CREAT | (truncate ? O_TRUNC : O_APPEND), 0644);
+  if (fd < 0) { fprintf(stderr, "Could not open log file %s\n", path); exit(1); }
+  dup2(fd, 1);
+  close(fd);
+}
+
+static char *field_or_null(char *s) { return (s == NULL || s[0] == 0 || strcmp(s, "-") == 0) ? NULL : s; }
+
+/* flat view of a core list for ramx_extend_batch (arrays owned by the caller's arena) */
+static void flatten_cores(struct coreAlignment *cores, int N, ramx_flat_cores *fc)
+{
+  int64_t *i64 = (int64_t *)malloc(sizeof(int64_t) * 4 * (size_t)(N + 1));
+  int8_t *i8 = (int8_t *)malloc(3 * (size_t)(N + 1));
+  int32_t *i32 = (int32_t *)calloc(3 * (size_t)(N + 1), sizeof(int32_t));
+  fc->n = N;
+  fc->left_pos = i64; fc->right_pos = i64 + N; fc->lower = i64 + 2 * N; fc->upper = i64 + 3 * N;
+  fc->orient = i8; fc->left_ext = i8 + N; fc->right_ext = i8 + 2 * N;
+  fc->left_len = i32; fc->right_len = i32 + N; fc->score = i32 + 2 * N;
+  int k = 0;
+  for (struct coreAlignment *c = cores; c != NULL && k < N; c = c->next, k++)
+  {
+    i64[k] = (int64_t)c->leftSeqPos; i64[N + k] = (int64_t)c->rightSeqPos;
+    i64[2 * N + k] = (int64_t)c->lowerSeqBound; i64[3 * N + k] = (int64_t)c->upperSeqBound;
+    i8[k] = c->orient ? 1 : 0; i8[N + k] = c->leftExtendable ? 1 : 0; i8[2 * N + k] = c->rightExtendable ? 1 : 0;
+    i32[k] = c->leftExtensionLen; i32[N + k] = c->rightExtensionLen; i32[2 * N + k] = c->score;
+  }
+}
+static void unflatten_results(struct coreAlignment *cores, const ramx_flat_cores *fc)
+{
+  int k = 0;
+  for (struct coreAlignment *c = cores; c != NULL && k < fc->n; c = c->next, k++)
+  {
+    c->leftExtensionLen = fc->left_len[k]; c->rightExtensionLen = fc->right_len[k]; c->score = fc->score[k];
+  }
+}
+static void free_flat(ramx_flat_cores *fc) { free((void *)fc->left_pos); free((void *)fc->orient); free(fc->left_len); }
+
+/* the lines extend_alignment prints around the loop (ram_extend.c:886-892, 1216-1231) */
+static void print_loop_lines(int direction, int N, int verbose, int when_to_stop, int L, const ramx_run_info *info, int before)
+{
+  if (before)
+  {
+    if (verbose >= 3) printf(direction ? "extend_alignment(right): Called with %d edges\n" : "extend_alignment(left): Called with %d edges\n", N);
+    return;
+  }
+  if (info->rows_executed > 0 && verbose >= 3)
+  {
+    const int last = info->rows_executed - 1;
+    if (abs(last - (info->ret - 1)) >= when_to_stop)
+      printf("Ending...due to row_idx=%d - max_extension_score_row_idx=%d <= -WHEN_TO_STOP=%d\n", last, info->ret - 1, when_to_stop);
+  }
+  if (info->limit_warning)
+    printf(direction ? "WARNING: Extended sequence right to the limit ( L=%d ).\n" : "WARNING: Extended sequence left to the limit ( L=%d ).\n", L);
+}
+
+static int run_batch(struct cli_opts *o, time_t t_start)
+{
+  const int L = o->L, l = 1;
+  if (o->outmat != NULL) { fprintf(stderr, "RAMExtend(ramx): -outmat is not available on the device path\n"); exit(1); }
+  FILE *lf = fopen(o->batch_file, "r");
+  if (!lf) { fprintf(stderr, "Could not open batch list %s\n", o->batch_file); exit(1); }
+  size_t cap = 64, F = 0;
+  struct batch_item *it = (struct batch_item *)calloc(cap, sizeof(*it));
+  char *line = NULL;
+  size_t lcap = 0;
+  ssize_t len;
+  while ((len = getline(&line, &lcap, lf)) >= 0)
+  {
+    while (len > 0 && (line[len - 1] == '\n' || line[len - 1] == '\r')) line[--len] = 0;
+    if (line[0] == '#' || line[0] == 0) continue;
+    char *f[5] = { NULL, NULL, NULL, NULL, NULL };
+    char *p = line;
+    for (int k = 0; k < 5 && p; k++) { f[k] = p; char *t = strchr(p, '\t'); if (t) { *t = 0; p = t + 1; } else p = NULL; }
+    if (!f[0] || !f[1]) { fprintf(stderr, "batch list: every line needs at least <ranges><TAB><log>\n"); exit(1); }
+    if (F == cap) { cap *= 2; it = (struct batch_item *)realloc(it, cap * sizeof(*it)); memset(it + F, 0, (cap - F) * sizeof(*it)); }
+    it[F].ranges = strdup(f[0]); it[F].log = strdup(f[1]);
+    it[F].cons = field_or_null(f[2]) ? strdup(f[2]) : NULL;
+    it[F].tsv = field_or_null(f[3]) ? strdup(f[3]) : NULL;
+    it[F].fa = field_or_null(f[4]) ? strdup(f[4]) : NULL;
+    F++;
+  }
+  free(line);
+  fclose(lf);
+  fflush(stdout);
+  const int saved = dup(1);
+
+  /* phase 1: load every family; its log gets the banner, the parameters and the core table */
+  ramx_family *fam = (ramx_family *)calloc(F ? F : 1, sizeof(*fam));
+  for (size_t i = 0; i < F; i++)
+  {
+    to_log(it[i].log, 1);
+    it[i].lib = ramx_load_sequence_subset_minimal(o->seq_file, it[i].ranges, &it[i].cores, &it[i].N, L + o->bandwidth);
+    print_header(o, it[i].ranges, it[i].N, it[i].lib);
+    ramx_print_core_edges(it[i].cores, it[i].lib, 0, o->verbose ? 1 : 0);
+    it[i].master = (char *)calloc((size_t)(2 * (long)L + l + 1), 1);
+    it[i].master[L] = RAMX_SYM_N;
+    fam[i].sequence = (const int8_t *)it[i].lib->sequence;
+    fam[i].seq_len = it[i].lib->length;
+    fam[i].master = (int8_t *)it[i].master;
+  }
+  fflush(stdout);
+  dup2(saved, 1);
+
+  int32_t *mflat = (int32_t *)calloc(100 * 100, sizeof(int32_t));
+  for (int a = 0; a < 4; a++)
+  {
+    for (int b = 0; b < 8; b++) mflat[a * 100 + b] = o->sp->matrix[a][b];
+    mflat[a * 100 + RAMX_SYM_N] = o->sp->matrix[a][RAMX_SYM_N];
+  }
+  ramx_params p;
+  p.bandwidth = o->bandwidth; p.cappenalty = o->cappenalty; p.minimprovement = o->minimprovement; p.L = L;
+  p.when_to_stop = o->when_to_stop; p.l = l; p.gapopen = o->sp->gapopen; p.gapextn = o->sp->gapextn; p.matrix = mflat;
+  ramx_run_info *ir = (ramx_run_info *)calloc(F ? F : 1, sizeof(*ir)), *il = (ramx_run_info *)calloc(F ? F : 1, sizeof(*il));
+
+  /* phase 2: right extension of all families in one launch; phase 3: per family, overlap avoidance */
+  for (size_t i = 0; i < F; i++) flatten_cores(it[i].cores, it[i].N, &fam[i].cores);
+  if (ramx_extend_batch(1, fam, (int32_t)F, &p, ir) < 0) { fprintf(stderr, "RAMExtend(ramx): batch extension failed: %s\n", ramx_last_error()); exit(1); }
+  for (size_t i = 0; i < F; i++)
+  {
+    unflatten_results(it[i].cores, &fam[i].cores);
+    free_flat(&fam[i].cores);
+    it[i].rightbp = ir[i].ret;
+    to_log(it[i].log, 0);
+    print_loop_lines(1, it[i].N, o->verbose, o->when_to_stop, L, &ir[i], 1);
+    print_loop_lines(1, it[i].N, o->verbose, o->when_to_stop, L, &ir[i], 0);
+    printf("Extended right: %d bp\n", it[i].rightbp);
+    ramx_overlap_avoidance(it[i].cores, it[i].lib);
+  }
+  fflush(stdout);
+  dup2(saved, 1);
+
+  /* phase 4: left extension in one launch; phase 5: per family, results */
+  for (size_t i = 0; i < F; i++) flatten_cores(it[i].cores, it[i].N, &fam[i].cores);
+  if (ramx_extend_batch(0, fam, (int32_t)F, &p, il) < 0) { fprintf(stderr, "RAMExtend(ramx): batch extension failed: %s\n", ramx_last_error()); exit(1); }
+  for (size_t i = 0; i < F; i++)
+  {
+    unflatten_results(it[i].cores, &fam[i].cores);
+    free_flat(&fam[i].cores);
+    it[i].leftbp = il[i].ret;
+    to_log(it[i].log, 0);
+    print_loop_lines(0, it[i].N, o->verbose, o->when_to_stop, L, &il[i], 1);
+    print_loop_lines(0, it[i].N, o->verbose, o->when_to_stop, L, &il[i], 0);
+    printf("Extended left : %d bp\n", it[i].leftbp);
+    write_results(o, it[i].cores, it[i].lib, it[i].master, it[i].rightbp, it[i].leftbp, it[i].cons, it[i].tsv, it[i].fa);
+    const double duration = difftime(time(0), t_start);
+    printf("Program duration is %.1f sec = %.1f min = %.1f hr\n", duration, duration / 60.0, duration / 3600.0);
+  }
+  fflush(stdout);
+  dup2(saved, 1);
+  close(saved);
+  printf("RAMExtend(ramx) batch: %zu families done\n", F);
+  for (size_t i = 0; i < F; i++)
+  {
+    ramx_free_library(it[i].lib, it[i].cores);
+    free(it[i].master); free(it[i].ranges); free(it[i].log); free(it[i].cons); free(it[i].tsv); free(it[i].fa);
+  }
+  free(it); free(fam); free(ir); free(il); free(mflat);
+  ramx_free_scoring_system(o->sp);
+  return 0;
+}
+
+int ramx_cli_main(int argc, char **argv)
+{
+  const time_t t_start = time(0);
+  struct cli_opts o;
+  memset(&o, 0, sizeof(o));
+  const int l = 1;
+
+  if (opt_bool(argc, argv, "-version"))
+  {
+    printf("RAMExtend Version %s - build %s date %s\n", k_version, k_build, k_build_date);
+    exit(0);
+  }
+  opt_string(argc, argv, "-batch", &o.batch_file);
+  if (!opt_string(argc, argv, "-ranges", &o.ranges_file) && !o.batch_file) usage();
+
+  opt_int(argc, argv, "-addflanking", &o.flanking);
+  opt_string(argc, argv, "-outtsv", &o.outtsv);
+  opt_string(argc, argv, "-outfa", &o.outfa);
+  opt_string(argc, argv, "-outmat", &o.outmat);
+  opt_string(argc, argv, "-cons", &o.cons_file);
+  if (!opt_int(argc, argv, "-L", &o.L)) o.L = 10000;
+  if (!opt_int(argc, argv, "-bandwidth", &o.bandwidth)) o.bandwidth = 14;
+  if (!opt_int(argc, argv, "-maxoccurrences", &o.maxn)) o.maxn = 10000;
+  if (!opt_int(argc, argv, "-stopafter", &o.when_to_stop)) o.when_to_stop = 100;
+  if (!opt_int(argc, argv, "-threads", &o.num_threads)) o.num_threads = 0;
+  o.verbose = opt_bool(argc, argv, "-vvvvvv") ? 20 : opt_bool(argc, argv, "-vvvvv") ? 12 :
+              opt_bool(argc, argv, "-vvvv") ? 10 : opt_bool(argc, argv, "-vvv") ? 3 :
+              opt_bool(argc, argv, "-vv") ? 2 : opt_bool(argc, argv, "-v") ? 1 : 0;
+
+  if (!opt_string(argc, argv, "-matrix", &o.matrix_name)) o.matrix_name = "20p43g";
+  if (o.matrix_name == NULL) o.matrix_name = "";
+  o.is_rs = strcmp(o.matrix_name, "repeatscout") == 0;
+  if (o.is_rs)
+  {
+    if (opt_int(argc, argv, "-match", &o.match) && opt_int(argc, argv, "-mismatch", &o.mismatch) &&
+        opt_int(argc, argv, "-gap", &o.gap_ext))
+      o.sp = ramx_get_repeatscout_matrix(o.match, o.mismatch, o.gap_ext);
+    else
+      o.sp = ramx_get_repeatscout_matrix(1, -1, -5);
+  }
+  else
+  {
+    if (opt_int(argc, argv, "-gapopen", &o.gap_open) && opt_int(argc, argv, "-gapext", &o.gap_ext))
+      o.sp = ramx_get_matrix_using_gap_penalties(o.matrix_name, o.gap_open, o.gap_ext);
+    else
+      o.sp = ramx_get_matrix(o.matrix_name);
+  }
+  /* per-matrix defaults, ram_extend.c:301-344 */
+  {
+    int def_min, def_cap;
+    if (!strcmp(o.matrix_name, "14p43g") || !strcmp(o.matrix_name, "18p43g") || !strcmp(o.matrix_name, "20p43g")) { def_min = 27; def_cap = -90; }
+    else if (!strcmp(o.matrix_name, "25p43g")) { def_min = 24; def_cap = -90; }
+    else if (o.is_rs) { def_min = 3; def_cap = -20; }
+    else { printf("Matrix name not found!\n"); exit(1); }
+    if (!opt_int(argc, argv, "-minimprovement", &o.minimprovement)) o.minimprovement = def_min;
+    if (!opt_int(argc, argv, "-cappenalty", &o.cappenalty)) o.cappenalty = def_cap;
+  }
+  if (!opt_string(argc, argv, "-twobit", &o.seq_file))
+  {
+    if (opt_string(argc, argv, "-sequence", &o.seq_file))
+    {
+      printf("-sequence is deprecated!....may return someday\n");
+      exit(1);
+    }
+    usage();
+  }
+  if (o.batch_file) return run_batch(&o, t_start);
+
+  const int L = o.L;
+  char *master = (char *)malloc((size_t)(2 * (long)L + l + 1));
+  if (!master) { fprintf(stderr, "Could not allocate space for master array\n"); exit(1); }
+  memset(master, 0, (size_t)(2 * (long)L + l + 1));
+
+  struct coreAlignment *cores = NULL;
+  int N = 0;
+  struct sequenceLibrary *lib = ramx_load_sequence_subset_minimal(o.seq_file, o.ranges_file, &cores, &N, L + o.bandwidth);
+  if (o.outmat != NULL)
+  {
+    fprintf(stderr, "RAMExtend(ramx): -outmat (per-cell DP path dump) is not available on the device path\n");
+    exit(1);
+  }
+  print_header(&o, o.ranges_file, N, lib);
+  ramx_print_core_edges(cores, lib, 0, o.verbose ? 1 : 0);
+  master[L] = RAMX_SYM_N;   /* the l = 1 spacer, never printed (ram_extend.c:415-416) */
+
+  ramx_set_runtime(o.verbose, o.when_to_stop, l);
+  fflush(stdout);
+  int rightbp = ramx_extend_alignment(1, cores, NULL, lib, master, o.bandwidth, o.cappenalty, o.minimprovement, L, N, o.sp, NULL);
+  printf("Extended right: %d bp\n", rightbp);
+  ramx_overlap_avoidance(cores, lib);
+  int leftbp = ramx_extend_alignment(0, cores, NULL, lib, master, o.bandwidth, o.cappenalty, o.minimprovement, L, N, o.sp, NULL);
+  printf("Extended left : %d bp\n", leftbp);
+  write_results(&o, cores, lib, master, rightbp, leftbp, o.cons_file, o.outtsv, o.outfa);
+
   const double duration = difftime(time(0), t_start);
   printf("Program duration is %.1f sec = %.1f min = %.1f hr\n", duration, duration / 60.0, duration / 3600.0);
-  ramx_free_scoring_system(sp);
+  ramx_free_scoring_system(o.sp);
   ramx_free_library(lib, cores);
   free(master);
   return 0;
