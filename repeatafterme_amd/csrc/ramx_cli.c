@@ -160,6 +160,24 @@ static void write_wrapped(FILE *fp, const char *master, uint64_t from, uint64_t 
 }
 
 
+/* RAMX_TIMING=1: phase timings on stderr (stdout stays byte-compatible) */
+static double now_s(void)
+{
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+static int g_timing = 0;
+static double g_t_last = 0;
+static void phase_done(const char *what)
+{
+  if (!g_timing) return;
+  fflush(stdout);
+  const double t = now_s();
+  fprintf(stderr, "RAMX_TIMING %-18s %10.3f ms\n", what, (t - g_t_last) * 1e3);
+  g_t_last = t;
+}
+
 /* everything the command line decides */
 struct cli_opts
 {
@@ -587,6 +605,8 @@ int ramx_cli_main(int argc, char **argv)
   }
   if (o.batch_file) return run_batch(&o, t_start);
 
+  g_timing = getenv("RAMX_TIMING") != NULL;
+  g_t_last = now_s();
   const int L = o.L;
   char *master = (char *)malloc((size_t)(2 * (long)L + l + 1));
   if (!master) { fprintf(stderr, "Could not allocate space for master array\n"); exit(1); }
@@ -600,18 +620,24 @@ int ramx_cli_main(int argc, char **argv)
     fprintf(stderr, "RAMExtend(ramx): -outmat (per-cell DP path dump) is not available on the device path\n");
     exit(1);
   }
+  phase_done("load");
   print_header(&o, o.ranges_file, N, lib);
   ramx_print_core_edges(cores, lib, 0, o.verbose ? 1 : 0);
+  phase_done("core table");
   master[L] = RAMX_SYM_N;   /* the l = 1 spacer, never printed (ram_extend.c:415-416) */
 
   ramx_set_runtime(o.verbose, o.when_to_stop, l);
   fflush(stdout);
   int rightbp = ramx_extend_alignment(1, cores, NULL, lib, master, o.bandwidth, o.cappenalty, o.minimprovement, L, N, o.sp, NULL);
   printf("Extended right: %d bp\n", rightbp);
+  phase_done("extend right");
   ramx_overlap_avoidance(cores, lib);
+  phase_done("overlap avoidance");
   int leftbp = ramx_extend_alignment(0, cores, NULL, lib, master, o.bandwidth, o.cappenalty, o.minimprovement, L, N, o.sp, NULL);
   printf("Extended left : %d bp\n", leftbp);
+  phase_done("extend left");
   write_results(&o, cores, lib, master, rightbp, leftbp, o.cons_file, o.outtsv, o.outfa);
+  phase_done("report + outputs");
 
   const double duration = difftime(time(0), t_start);
   printf("Program duration is %.1f sec = %.1f min = %.1f hr\n", duration, duration / 60.0, duration / 3600.0);

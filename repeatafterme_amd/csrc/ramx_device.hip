@@ -169,6 +169,24 @@ __device__ __forceinline__ long long wave_sum_ll(long long v)
   return v;
 }
 
+// Sum over the wave of a value in [0, 2^31) per lane, without touching LDS: two 32-bit DPP reductions (low and high
+// 16 bits; 64 lanes x 2^16 fits), total read from lane 63.  Six VALU steps each instead of six ds_bpermute pairs.
+__device__ __forceinline__ unsigned wave_sum_u32_dpp(unsigned v)
+{
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false);    // quad_perm:[1,0,3,2]
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false);    // quad_perm:[2,3,0,1]
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xf, 0xf, false);   // row_ror:4
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, false);   // row_ror:8  -> row totals everywhere
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ long long wave_sum_nonneg31(int v)
+{
+  const unsigned lo = wave_sum_u32_dpp((unsigned)v & 0xffffu), hi = wave_sum_u32_dpp((unsigned)v >> 16);
+  return ((long long)hi << 16) + (long long)lo;
+}
+
 // The DP rows are written once per column and read once by the next launch.  Plain (cacheable) accesses are the
 // measured choice: the 131 MB ping-pong working set of the N = 100,000 workload stays largely resident in the
 // 256 MB Infinity Cache between launches; non-temporal accesses (-DRAMX_NT_LDST) were 25 % slower
@@ -555,7 +573,7 @@ __global__ __launch_bounds__(BLOCK) void ramx_column_kernel(const KArgs a)
   __syncthreads();
 
   // ---- the band: one lane = one flank -----------------------------------------------------
-  long long contrib[4] = { 0, 0, 0, 0 };
+  int contrib[4] = { 0, 0, 0, 0 };              // each in [0, 2^31)
   if (live)
   {
     const int jlo = bd.x - r, jhi = bd.y - r;        // cell j (row r) / j-1 (row r+1) is in bounds iff jlo <= j <= jhi
@@ -582,12 +600,15 @@ __global__ __launch_bounds__(BLOCK) void ramx_column_kernel(const KArgs a)
   }
 
   // ---- 64 lanes -> wave -> block -> one int64 atomic per candidate into this block's shard ----
-#pragma unroll
-  for (int c = 0; c < 4; c++) contrib[c] = wave_sum_ll(contrib[c]);
-  if (lane == 0)
   {
+    long long tot[4];
 #pragma unroll
-    for (int c = 0; c < 4; c++) s_red[wave][c] = contrib[c];
+    for (int c = 0; c < 4; c++) tot[c] = wave_sum_nonneg31(contrib[c]);
+    if (lane == 0)
+    {
+#pragma unroll
+      for (int c = 0; c < 4; c++) s_red[wave][c] = tot[c];
+    }
   }
   __syncthreads();
   if (threadIdx.x < 4)
@@ -652,20 +673,115 @@ struct PArgs
   int rank, nranks;
   int Np, Nx, r0, L, go, ge, cap, minimp, when_to_stop, nblocks;
   int tab[RAMX_NCLASS][4];
+  unsigned long long *dbg;      // -DRAMX_PRK_TIMING builds only: [block][8] phase sums in 10 ns ticks
 };
 
 #define PRK_SPIN_LIMIT (1u << 22)
+#ifdef RAMX_PRK_TIMING
+#define PRK_TICK(k) do { const unsigned long long t_ = wall_clock64(); tsum[k] += t_ - tlast; tlast = t_; } while (0)
+#else
+#define PRK_TICK(k) do { } while (0)
+#endif
 
 // Row state of the persistent kernel: m[B] in registers; e is kept as the 16-bit difference d = e - m in LDS.
 // With go <= 0:  m + go + ge <= e <= m + ge  (e = max(sub+go, gap) + ge, m = max(sub, gap)), so d lies in
 // [go + ge, ge] and int16 is exact whenever go + ge >= -32768 (checked on the host).  Each lane owns one dword per
 // cell pair (layout [j/2][thread] dwords, halves by parity of j): conflict-free ds_read_i16 / ds_write_b16.
+#ifndef PRK_OOB_GROUP
+#define PRK_OOB_GROUP 2
+#endif
+#ifndef PRK_FAST_GROUP
+#define PRK_FAST_GROUP 8
+#endif
+__device__ __forceinline__ int vmax3(int x, int y, int z)   // forced v_max3_i32 (keeps the compiler from re-associating)
+{
+  int d;
+  asm("v_max3_i32 %0, %1, %2, %3" : "=v"(d) : "v"(x), "v"(y), "v"(z));
+  return d;
+}
+
+// In-bounds, chain-free band of the register-resident kernels (the steady state of a run): per cell
+//   sub = Pm + sF;  m = max3(sub, eC, Pe);  e = max3(sub + go, eC, Pe) + ge          (5 VALU, chain of 2)
+// and the four candidates take two cells per v_max3; their shared deletion term max_k e_k is folded in at the end.
+template <int W, int BLOCK>
+__device__ __forceinline__ void prk_band_fast(const int go, const int ge, const int *s_tab, short *sD, const int r,
+                                              const unsigned (&w)[(2 * W + 1 + 8) / 8 + 2], int (&M)[2 * W + 1], LaneDP &D)
+{
+  constexpr int B = 2 * W + 1;
+  const int ph4 = 4 * ((r + 8) & 7);
+  short *myD = sD + 2 * threadIdx.x;
+  int eC = NEG, mPrev = NEG, bestF = NEG, jbest = 0, maxE = NEG, ePend = NEG;
+  int bA[4] = { NEG, NEG, NEG, NEG }, pend[4] = { NEG, NEG, NEG, NEG };
+#pragma unroll
+  for (int j = 0; j <= B; j++)
+  {
+    if ((j & (PRK_FAST_GROUP - 1)) == 0)
+    {
+      // pin the candidates' accumulators to their 8-step group: nothing but data dependences orders pure arithmetic
+      // against sched_barrier during instruction selection, and a sunk accumulation keeps every table row alive
+      asm volatile("" ::"v"(bA[0]), "v"(bA[1]), "v"(bA[2]), "v"(bA[3]), "v"(maxE), "v"(bestF), "v"(jbest));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    const unsigned A = __builtin_amdgcn_alignbit(w[(j >> 3) + 1], w[j >> 3], ph4);
+    const unsigned bc = (A >> (4 * (j & 7))) & 15u;
+    const int4 sv = *reinterpret_cast<const int4 *>(s_tab + bc * TAB_STRIDE);
+    // candidates' cell j-1 of row r+1: substitution from m_{j-1} of row r (the base of that cell is this step's)
+    if (j >= 1)
+    {
+      const int t4[4] = { mPrev + sv.x, mPrev + sv.y, mPrev + sv.z, mPrev + sv.w };
+      if (j & 1)
+      {
+#pragma unroll
+        for (int c = 0; c < 4; c++) pend[c] = t4[c];
+      }
+      else
+      {
+#pragma unroll
+        for (int c = 0; c < 4; c++) bA[c] = imax3(bA[c], pend[c], t4[c]);
+      }
+    }
+    if (j < B)
+    {
+      const int sF = s_tab[bc * TAB_STRIDE + 4];
+      const int Pm = M[j];
+      int Pe = NEG;
+      if (j + 1 < B) Pe = M[j + 1] + (int)myD[((j + 1) >> 1) * (2 * BLOCK) + ((j + 1) & 1)];
+      const int sub = Pm + sF;                       // bnw_extend.c:950-956
+      const int m = vmax3(sub, eC, Pe);              // max(sub, max(ins, del)), :1007-1018
+      const int e = vmax3(sub + go, eC, Pe) + ge;
+      const bool better = m > bestF;                 // :1020-1024 strict >: lowest offset wins ties
+      bestF = imax(m, bestF);
+      jbest = better ? j : jbest;
+      M[j] = m;
+      myD[(j >> 1) * (2 * BLOCK) + (j & 1)] = (short)(e - m);
+      // deletion term of candidate cell j-1 is e_j (cells 1..B-1)
+      if (j >= 1)
+      {
+        if (j & 1) ePend = e;
+        else maxE = imax3(maxE, ePend, e);
+      }
+      mPrev = m;
+      eC = e;
+    }
+  }
+  // B is odd: the last candidate term (step B) is still pending; B-1 is even: every e has been folded
+#pragma unroll
+  for (int c = 0; c < 4; c++) D.bestA[c] = imax3(bA[c], (B & 1) ? pend[c] : NEG, maxE);
+  D.bestF = bestF;
+  D.jbest = jbest;
+}
+
 template <int W, bool OOB, int BLOCK, bool INIT = false>
 __device__ __forceinline__ void prk_band(const int go, const int ge, const int *s_tab, short *sD, const int r,
                                          const unsigned (&w)[(2 * W + 1 + 8) / 8 + 2], const int jlo, const int jhi,
                                          int (&M)[2 * W + 1], LaneDP &D)
 {
   constexpr int B = 2 * W + 1;
+  if (!OOB && !INIT)
+  {
+    prk_band_fast<W, BLOCK>(go, ge, s_tab, sD, r, w, M, D);
+    return;
+  }
   const int edgeF = (r < W) ? go + (r + 1) * ge : SENT;
   const int edgeC = (r + 1 < W) ? go + (r + 2) * ge : SENT;
   const int ph4 = 4 * ((r + 8) & 7);
@@ -674,8 +790,8 @@ __device__ __forceinline__ void prk_band(const int go, const int ge, const int *
   for (int j = 0; j <= B; j++)
   {
     // the row itself occupies B registers: keep the scheduler from hoisting every table lookup of the fully
-    // unrolled band to the top; lookups may run at most one 8-step group ahead
-    if ((j & 7) == 0) __builtin_amdgcn_sched_barrier(0);
+    // unrolled band to the top.  This is the rarely taken masked path: small groups, lowest register pressure
+    if ((j & (PRK_OOB_GROUP - 1)) == 0) __builtin_amdgcn_sched_barrier(0);
     const unsigned A = __builtin_amdgcn_alignbit(w[(j >> 3) + 1], w[j >> 3], ph4);
     const unsigned bc = (A >> (4 * (j & 7))) & 15u;
     StepU u;
@@ -728,12 +844,13 @@ __global__ __launch_bounds__(BLOCK, 2) void ramx_persistent_kernel(const PArgs a
       M[2 * q] = v.x; M[2 * q + 1] = v.z;
       myD[q * RS] = (short)(v.y - v.x); myD[q * RS + 1] = (short)(v.w - v.z);
     }
+    __builtin_amdgcn_sched_barrier(0);
     const int4 v = S[(size_t)W * 64];
     M[B - 1] = v.x; myD[W * RS] = (short)(v.y - v.x); high = v.z; pos = v.w;
   }
   const int2 bd = a.bounds[n];
   const int shard = blockIdx.x % NSHARD;
-  const int my_shard_blocks = (a.nblocks - lane + NSHARD - 1) / NSHARD;   // wave 0, lane < 32: blocks arriving on shard `lane`
+  const int my_shard_blocks = (a.nblocks - (lane & (NSHARD - 1)) + NSHARD - 1) / NSHARD;   // wave 0: blocks arriving on shard `lane & 31`
 
   long long max_ext = 0;
   int max_row = -1, rows_done = 0, ovf = 0, stopped = 0, failed = 0;
@@ -746,8 +863,12 @@ __global__ __launch_bounds__(BLOCK, 2) void ramx_persistent_kernel(const PArgs a
     s_tab4[bt][e] = v;
   }
 
+#ifdef RAMX_PRK_TIMING
+  unsigned long long tsum[6] = { 0, 0, 0, 0, 0, 0 }, tlast = wall_clock64();
+#endif
   for (int r = 0; r < a.L; r++)
   {
+    PRK_TICK(5);
     // ---- base words of this column (independent of the vote: issued before the wait) -------
     unsigned w[NW];
     {
@@ -765,18 +886,23 @@ __global__ __launch_bounds__(BLOCK, 2) void ramx_persistent_kernel(const PArgs a
       }
       else
       {
-        PShard *sh = a.vote + (size_t)(r % 3) * NSHARD + (lane < NSHARD ? lane : 0);
+        // lane = shard + 32 * half polls words 2*half, 2*half+1 of "its" shard: one 16-byte load per lane and round
+        // (a quarter of the requests of four 8-byte loads on 32 lanes; the poll competes with the adds it waits for)
+        const int sidx = lane & (NSHARD - 1), half = lane >> 5;
+        const unsigned long long *src = &a.vote[(size_t)(r % 3) * NSHARD + sidx].word[2 * half];
         unsigned spins = 0;
-        bool done = lane >= NSHARD || my_shard_blocks <= 0 || (a.nranks > 1 && blockIdx.x != 0);   // multi-rank: only the exchanger needs the local total
-        unsigned long long x[4] = { 0, 0, 0, 0 };
+        bool done = my_shard_blocks <= 0 || (a.nranks > 1 && blockIdx.x != 0);   // multi-rank: only the exchanger needs the local total
+        unsigned long long x0 = 0, x1 = 0;
         for (;;)
         {
           if (!done)
           {
-#pragma unroll
-            for (int k = 0; k < 4; k++) x[k] = __hip_atomic_load(&sh->word[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            done = (x[0] >> 54) >= (unsigned long long)my_shard_blocks && (x[1] >> 54) >= (unsigned long long)my_shard_blocks &&
-                   (x[2] >> 54) >= (unsigned long long)my_shard_blocks && (x[3] >> 54) >= (unsigned long long)my_shard_blocks;
+            typedef unsigned v4u __attribute__((ext_vector_type(4)));
+            v4u q;
+            asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(q) : "v"(src) : "memory");
+            x0 = ((unsigned long long)q.y << 32) | q.x;
+            x1 = ((unsigned long long)q.w << 32) | q.z;
+            done = (x0 >> 54) >= (unsigned long long)my_shard_blocks && (x1 >> 54) >= (unsigned long long)my_shard_blocks;
           }
           if (__all(done)) break;
           if (++spins > PRK_SPIN_LIMIT || ((spins & 1023u) == 0 && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0))
@@ -786,15 +912,22 @@ __global__ __launch_bounds__(BLOCK, 2) void ramx_persistent_kernel(const PArgs a
           }
           __builtin_amdgcn_s_sleep(1);
         }
-        if (lane < NSHARD && my_shard_blocks > 0 && !failed && !(a.nranks > 1 && blockIdx.x != 0))
+        long long y0 = 0, y1 = 0;
+        if (my_shard_blocks > 0 && !failed && !(a.nranks > 1 && blockIdx.x != 0))
         {
-#pragma unroll
-          for (int k = 0; k < 4; k++)
-            v[k] = (long long)(x[k] & (PRK_TICKET - 1)) - (long long)(x[k] >> 54) * (long long)PRK_BIAS;
+          y0 = (long long)(x0 & (PRK_TICKET - 1)) - (long long)(x0 >> 54) * (long long)PRK_BIAS;
+          y1 = (long long)(x1 & (PRK_TICKET - 1)) - (long long)(x1 >> 54) * (long long)PRK_BIAS;
         }
-      }
+        // fold the 32 shards inside each half-wave; lanes 0 / 32 end up with words {0,1} / {2,3}
 #pragma unroll
-      for (int k = 0; k < 4; k++) v[k] = wave_sum_ll(v[k]);
+        for (int m = 16; m >= 1; m >>= 1) { y0 += __shfl_xor(y0, m, 64); y1 += __shfl_xor(y1, m, 64); }
+        v[0] = __shfl(y0, 0, 64); v[1] = __shfl(y1, 0, 64); v[2] = __shfl(y0, 32, 64); v[3] = __shfl(y1, 32, 64);
+      }
+      if (r == 0)
+      {
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = wave_sum_ll(v[k]);
+      }
       if (a.nranks > 1 && r > 0 && !failed)
       {
         // ---- cross-device step: v[] is this rank's total (identical in all lanes) -----------
@@ -841,14 +974,20 @@ __global__ __launch_bounds__(BLOCK, 2) void ramx_persistent_kernel(const PArgs a
         if (failed) __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
+    PRK_TICK(0);                 // wave 0: vote seen (other waves: nothing)
     __syncthreads();
-    if (s_fail) { failed = 1; break; }
+    PRK_TICK(1);                 // released by the block barrier
+    if (__builtin_amdgcn_readfirstlane(s_fail)) { failed = 1; break; }
     long long curr = 0;
     int besta = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++)
     {
-      const long long vk = s_vote[k];
+      // the vote is wave-uniform: move it to scalar registers so that the whole stop rule runs on the SALU and
+      // none of its state (max_ext, max_row, ...) occupies vector registers next to the row
+      const long long vv = s_vote[k];
+      const long long vk = ((long long)__builtin_amdgcn_readfirstlane((int)(vv >> 32)) << 32) |
+                           (long long)(unsigned)__builtin_amdgcn_readfirstlane((int)vv);
       if (vk > 2147483647LL || vk < -2147483648LL) ovf = 1;
       if (vk > curr) { curr = vk; besta = k; }
     }
@@ -871,7 +1010,7 @@ __global__ __launch_bounds__(BLOCK, 2) void ramx_persistent_kernel(const PArgs a
     const int *s_tab = s_tab4[besta];                // column 4 of table `besta` holds M[besta][class]
 
     // ---- the band, rows in registers ---------------------------------------------------------
-    long long contrib[4] = { 0, 0, 0, 0 };
+    int contrib[4] = { 0, 0, 0, 0 };       // each in [0, 2^31): clamped at 0 below, capped from below by high + cap
     if (live)
     {
       const int jlo = bd.x - r, jhi = bd.y - r;
@@ -895,15 +1034,20 @@ __global__ __launch_bounds__(BLOCK, 2) void ramx_persistent_kernel(const PArgs a
         }
       }
     }
+    PRK_TICK(2);                 // band done
     if (stopped || r == a.L - 1) break;     // the vote of row r+1 will not be consumed
-#pragma unroll
-    for (int c = 0; c < 4; c++) contrib[c] = wave_sum_ll(contrib[c]);
-    if (lane == 0)
     {
+      long long tot[4];
 #pragma unroll
-      for (int c = 0; c < 4; c++) s_red[wave][c] = contrib[c];
+      for (int c = 0; c < 4; c++) tot[c] = wave_sum_nonneg31(contrib[c]);
+      if (lane == 0)
+      {
+#pragma unroll
+        for (int c = 0; c < 4; c++) s_red[wave][c] = tot[c];
+      }
     }
     __syncthreads();
+    PRK_TICK(3);                 // wave reduction + block barrier
     if (blockIdx.x == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // block 0: its zeroing stores first
     if (threadIdx.x < 4)
     {
@@ -914,14 +1058,25 @@ __global__ __launch_bounds__(BLOCK, 2) void ramx_persistent_kernel(const PArgs a
       __hip_atomic_fetch_add(&sh->word[threadIdx.x], (unsigned long long)t + PRK_BIAS + PRK_TICKET, __ATOMIC_RELAXED,
                              __HIP_MEMORY_SCOPE_AGENT);
     }
+    PRK_TICK(4);                 // contribution issued
   }
+#ifdef RAMX_PRK_TIMING
+  if (a.dbg != NULL && (threadIdx.x & 63) == 0)
+  {
+#pragma unroll
+    for (int k = 0; k < 6; k++) a.dbg[((size_t)blockIdx.x * WPB + wave) * 8 + k] = tsum[k];
+  }
+#endif
 
   // ---- write back: rows (so that the device state can be inspected / resumed), trim, control ----
   if (live)
   {
 #pragma unroll
     for (int q = 0; q < W; q++)
+    {
       S[(size_t)q * 64] = make_int4(M[2 * q], M[2 * q] + (int)myD[q * RS], M[2 * q + 1], M[2 * q + 1] + (int)myD[q * RS + 1]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
     S[(size_t)W * 64] = make_int4(M[B - 1], M[B - 1] + (int)myD[W * RS], high, pos);
     a.trim[n] = make_int2(thigh, tpos);
   }
@@ -1023,7 +1178,7 @@ __global__ __launch_bounds__(BLOCK, 2) void ramx_family_kernel(const FArgs a)
       if (threadIdx.x == 0) a.cons_out[(size_t)blockIdx.x * a.L + r] = (signed char)besta;
     }
     const int *s_tab = s_tab4[besta];
-    long long contrib[4] = { 0, 0, 0, 0 };
+    int contrib[4] = { 0, 0, 0, 0 };
     if (live)
     {
       const int jlo = bd.x - r, jhi = bd.y - r;
@@ -1053,12 +1208,15 @@ __global__ __launch_bounds__(BLOCK, 2) void ramx_family_kernel(const FArgs a)
       }
     }
     if (stopped || r == a.L - 1) break;
-#pragma unroll
-    for (int c = 0; c < 4; c++) contrib[c] = wave_sum_ll(contrib[c]);
-    if (lane == 0)
     {
+      long long tot[4];
 #pragma unroll
-      for (int c = 0; c < 4; c++) s_red[(r + 1) & 1][wave][c] = contrib[c];
+      for (int c = 0; c < 4; c++) tot[c] = wave_sum_nonneg31(contrib[c]);
+      if (lane == 0)
+      {
+#pragma unroll
+        for (int c = 0; c < 4; c++) s_red[(r + 1) & 1][wave][c] = tot[c];
+      }
     }
     __syncthreads();
   }
@@ -1454,9 +1612,43 @@ static int prk_run(ramx_dev *d, const KArgs &a, int L, bool *used)
   HIPCHK(hipMemsetAsync(d->d_vote, 0, 3 * NSHARD * sizeof(PShard), d->stream));
   HIPCHK(hipMemsetAsync(d->d_err, 0, 64, d->stream));
   *used = true;
+#ifdef RAMX_PRK_TIMING
+  const size_t nw = (size_t)blocks * (block / 64);
+  HIPCHK(hipMalloc((void **)&pa.dbg, nw * 8 * sizeof(unsigned long long)));
+  HIPCHK(hipMemset(pa.dbg, 0, nw * 8 * sizeof(unsigned long long)));
+#endif
   if (block == 256)
-    return (W == 14) ? prk_launch<14, 256>(d, pa, blocks) : (W == 20) ? prk_launch<20, 256>(d, pa, blocks) : prk_launch<40, 256>(d, pa, blocks);
-  return (W == 14) ? prk_launch<14, 512>(d, pa, blocks) : (W == 20) ? prk_launch<20, 512>(d, pa, blocks) : prk_launch<40, 512>(d, pa, blocks);
+    rc = (W == 14) ? prk_launch<14, 256>(d, pa, blocks) : (W == 20) ? prk_launch<20, 256>(d, pa, blocks) : prk_launch<40, 256>(d, pa, blocks);
+  else
+    rc = (W == 14) ? prk_launch<14, 512>(d, pa, blocks) : (W == 20) ? prk_launch<20, 512>(d, pa, blocks) : prk_launch<40, 512>(d, pa, blocks);
+#ifdef RAMX_PRK_TIMING
+  if (rc == RAMX_OK)
+  {
+    // debug build: phase breakdown per column, in ns (wall_clock64 ticks are 10 ns)
+    HIPCHK(hipStreamSynchronize(d->stream));
+    unsigned long long *h = (unsigned long long *)malloc(nw * 8 * sizeof(unsigned long long));
+    HIPCHK(hipMemcpy(h, pa.dbg, nw * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    static const char *nm[6] = { "wait vote", "block barrier 1", "band", "reduce+barrier 2", "issue atomics", "loop top" };
+    const int wpb = block / 64;
+    fprintf(stderr, "PRK_TIMING blocks %d x %d threads, L %d (ns per column)\n", blocks, block, L);
+    for (int k = 0; k < 6; k++)
+    {
+      double s0 = 0, sO = 0, mx = 0, mn = 1e30;
+      for (size_t i = 0; i < nw; i++)
+      {
+        const double v = 10.0 * (double)h[i * 8 + k] / L;
+        if ((int)(i % wpb) == 0) s0 += v; else sO += v;
+        if (v > mx) mx = v;
+        if (v < mn) mn = v;
+      }
+      fprintf(stderr, "PRK_TIMING %-18s wave0 avg %8.1f  other waves avg %8.1f  min %8.1f  max %8.1f\n", nm[k], s0 / blocks,
+              wpb > 1 ? sO / (double)(nw - blocks) : 0.0, mn, mx);
+    }
+    free(h);
+    (void)hipFree(pa.dbg);
+  }
+#endif
+  return rc;
 }
 
 // ---- batch mode -------------------------------------------------------------------------------
