@@ -33,6 +33,7 @@
 // flanks (N >= 64 k fills the chip).  No MFMA: integer max-plus recurrences, HBM-bound.
 
 #include <hip/hip_runtime.h>
+#include <utility>
 #include <rccl/rccl.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -673,6 +674,7 @@ struct PArgs
   int rank, nranks;
   int Np, Nx, r0, L, go, ge, cap, minimp, when_to_stop, nblocks;
   int tab[RAMX_NCLASS][4];
+  int pack_ok;                  // every reachable score fits 27 bits: the fast path may pack (score, cell) keys
   unsigned long long *dbg;      // -DRAMX_PRK_TIMING builds only: [block][8] phase sums in 10 ns ticks
 };
 
@@ -700,36 +702,136 @@ __device__ __forceinline__ int vmax3(int x, int y, int z)   // forced v_max3_i32
   return d;
 }
 
+template <class F, int... Js>
+__device__ __forceinline__ void static_for(F &&f, std::integer_sequence<int, Js...>)
+{
+  (f(std::integral_constant<int, Js>{}), ...);
+}
+
+// Score tables of the in-bounds fast path, addressed straight from the packed base stream with ONE SDWA instruction:
+// the eight nibbles of an aligned base word sit in four bytes; for the high nibble of byte n the LDS byte offset is
+// (byte & 0xF0) (16-byte rows indexed by class), for the low nibble it is (byte << 4) into a 256-row table whose row
+// depends on the low nibble only.  A row is {M[A][b] | M[C][b] | M[G][b] | M[T][b] as four int8, M[besta][b], -, -}:
+// one ds_read_b64 per cell; the candidates' scores are consumed by sign-extending SDWA adds.  Dword 1 is rewritten
+// for every column (the winner changes), by wave 0 / before a block barrier.  Requires every score in [-128, 127]
+// (checked on the host together with the key-packing bound).
+struct FastTabs
+{
+  int lo[256][4];
+  int hi[16][4];
+};
+
+template <int BYTE>
+__device__ __forceinline__ unsigned nib_lo_x16(unsigned A)   // ((A >> 8*BYTE) & 0xff) << 4
+{
+  unsigned d;
+  if (BYTE == 0) asm("v_lshlrev_b32_sdwa %0, 4, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(d) : "v"(A));
+  else if (BYTE == 1) asm("v_lshlrev_b32_sdwa %0, 4, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(d) : "v"(A));
+  else if (BYTE == 2) asm("v_lshlrev_b32_sdwa %0, 4, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(d) : "v"(A));
+  else asm("v_lshlrev_b32_sdwa %0, 4, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(d) : "v"(A));
+  return d;
+}
+template <int BYTE>
+__device__ __forceinline__ unsigned nib_hi_x16(unsigned A, unsigned mask_f0)   // (A >> 8*BYTE) & 0xf0
+{
+  unsigned d;
+  if (BYTE == 0) asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(d) : "s"(mask_f0), "v"(A));
+  else if (BYTE == 1) asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(d) : "s"(mask_f0), "v"(A));
+  else if (BYTE == 2) asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(d) : "s"(mask_f0), "v"(A));
+  else asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(d) : "s"(mask_f0), "v"(A));
+  return d;
+}
+
+template <int BYTE>
+__device__ __forceinline__ int add_sext_byte(int x, int packed)   // x + (int)(signed char)(packed >> 8*BYTE)
+{
+  int d;
+  if (BYTE == 0) asm("v_add_u32_sdwa %0, %1, sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(d) : "v"(x), "v"(packed));
+  else if (BYTE == 1) asm("v_add_u32_sdwa %0, %1, sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(d) : "v"(x), "v"(packed));
+  else if (BYTE == 2) asm("v_add_u32_sdwa %0, %1, sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(d) : "v"(x), "v"(packed));
+  else asm("v_add_u32_sdwa %0, %1, sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(d) : "v"(x), "v"(packed));
+  return d;
+}
+
+// candidate bytes: once per launch.
+template <int BLOCK>
+__device__ __forceinline__ void fast_tabs_init(FastTabs &ft, const int (&tab)[RAMX_NCLASS][4])
+{
+  for (int i = threadIdx.x; i < 256 + 16; i += BLOCK)
+  {
+    const int cls = i < 256 ? (i & 15) : (i - 256);
+    unsigned pk = 0;
+    if (cls < RAMX_NCLASS)
+      pk = ((unsigned)tab[cls][0] & 0xffu) | (((unsigned)tab[cls][1] & 0xffu) << 8) | (((unsigned)tab[cls][2] & 0xffu) << 16) |
+           (((unsigned)tab[cls][3] & 0xffu) << 24);
+    int *row = i < 256 ? ft.lo[i] : ft.hi[i - 256];
+    row[0] = (int)pk; row[1] = 0; row[2] = 0; row[3] = 0;
+  }
+}
+// winner dword of the column whose winner is `besta`: rows i, i + nthreads, ... of the 256 (+16) by thread i.
+__device__ __forceinline__ void fast_tabs_winner(FastTabs &ft, const int *tab_besta /* old-format table of besta */, int i, int nthreads)
+{
+  for (int row = i; row < 256; row += nthreads)
+  {
+    const int cls = row & 15;
+    ft.lo[row][1] = cls < RAMX_NCLASS ? tab_besta[cls * TAB_STRIDE + 4] : 0;
+  }
+  if (i < 16) ft.hi[i][1] = i < RAMX_NCLASS ? tab_besta[i * TAB_STRIDE + 4] : 0;
+}
+
 // In-bounds, chain-free band of the register-resident kernels (the steady state of a run): per cell
 //   sub = Pm + sF;  m = max3(sub, eC, Pe);  e = max3(sub + go, eC, Pe) + ge          (5 VALU, chain of 2)
-// and the four candidates take two cells per v_max3; their shared deletion term max_k e_k is folded in at the end.
+// The four candidates take two cells per v_max3; their shared deletion term max_k e_k is folded in at the end.
+// The best cell of the row (value, lowest index on ties: bnw_extend.c:1020-1024) is tracked as a packed key
+// (m << 4) | (15 - (j & 15)) per 16-cell group, two cells per v_max3; exact while |m| < 2^27 (checked on the host).
 template <int W, int BLOCK>
-__device__ __forceinline__ void prk_band_fast(const int go, const int ge, const int *s_tab, short *sD, const int r,
+__device__ __forceinline__ void prk_band_fast(const int go, const int ge, const FastTabs &ft, short *sD, const int r,
                                               const unsigned (&w)[(2 * W + 1 + 8) / 8 + 2], int (&M)[2 * W + 1], LaneDP &D)
 {
-  constexpr int B = 2 * W + 1;
+  constexpr int B = 2 * W + 1, NG = (B + 15) / 16;
   const int ph4 = 4 * ((r + 8) & 7);
+  const unsigned mask_f0 = 0xf0u;
   short *myD = sD + 2 * threadIdx.x;
-  int eC = NEG, mPrev = NEG, bestF = NEG, jbest = 0, maxE = NEG, ePend = NEG;
+  const char *t_lo = reinterpret_cast<const char *>(&ft.lo[0][0]), *t_hi = reinterpret_cast<const char *>(&ft.hi[0][0]);
+  int eC = NEG, mPrev = NEG, maxE = NEG, ePend = NEG, kPend = NEG;
   int bA[4] = { NEG, NEG, NEG, NEG }, pend[4] = { NEG, NEG, NEG, NEG };
+  int kg[NG];
 #pragma unroll
-  for (int j = 0; j <= B; j++)
+  for (int g = 0; g < NG; g++) kg[g] = -2147483647 - 1;
+  // compile-time cell index: the band is generated step by step (no reliance on the loop unroller, whose size limit
+  // would otherwise leave the row in scratch memory).  Table rows are fetched one step ahead of their use.
+  unsigned A = __builtin_amdgcn_alignbit(w[1], w[0], ph4);
+  int2 rowN = *reinterpret_cast<const int2 *>(t_lo + nib_lo_x16<0>(A));      // {candidate bytes, M[besta][base]}
+  int dN = (B > 1) ? (int)myD[1] : 0;               // e - m of the previous row's cell j+1, fetched one step ahead too
+  auto step = [&](auto jc) __attribute__((always_inline))
   {
-    if ((j & (PRK_FAST_GROUP - 1)) == 0)
+    constexpr int j = decltype(jc)::value;
+    if constexpr ((j & (PRK_FAST_GROUP - 1)) == 0)
     {
-      // pin the candidates' accumulators to their 8-step group: nothing but data dependences orders pure arithmetic
-      // against sched_barrier during instruction selection, and a sunk accumulation keeps every table row alive
-      asm volatile("" ::"v"(bA[0]), "v"(bA[1]), "v"(bA[2]), "v"(bA[3]), "v"(maxE), "v"(bestF), "v"(jbest));
+      // pin the accumulators to their group: nothing but data dependences orders pure arithmetic against
+      // sched_barrier during instruction selection, and a sunk accumulation keeps every table row alive
+      asm volatile("" ::"v"(bA[0]), "v"(bA[1]), "v"(bA[2]), "v"(bA[3]), "v"(maxE), "v"(kg[(j > 0 ? j - 1 : 0) >> 4]));
       __builtin_amdgcn_sched_barrier(0);
     }
-    const unsigned A = __builtin_amdgcn_alignbit(w[(j >> 3) + 1], w[j >> 3], ph4);
-    const unsigned bc = (A >> (4 * (j & 7))) & 15u;
-    const int4 sv = *reinterpret_cast<const int4 *>(s_tab + bc * TAB_STRIDE);
-    // candidates' cell j-1 of row r+1: substitution from m_{j-1} of row r (the base of that cell is this step's)
-    if (j >= 1)
+    const int sv = rowN.x, sF = rowN.y;
+    const int dCur = dN;
+    if constexpr (j + 2 < B) dN = (int)myD[((j + 2) >> 1) * (2 * BLOCK) + ((j + 2) & 1)];
+    if constexpr (j + 1 <= B)
     {
-      const int t4[4] = { mPrev + sv.x, mPrev + sv.y, mPrev + sv.z, mPrev + sv.w };
-      if (j & 1)
+      constexpr int jn = j + 1;
+      if constexpr ((jn & 7) == 0) A = __builtin_amdgcn_alignbit(w[(jn >> 3) + 1], w[jn >> 3], ph4);
+      constexpr bool lo = (jn & 1) == 0;
+      constexpr int byte = (jn & 7) / 2;
+      unsigned off;
+      if constexpr (lo) off = nib_lo_x16<byte>(A);
+      else off = nib_hi_x16<byte>(A, mask_f0);
+      rowN = *reinterpret_cast<const int2 *>((lo ? t_lo : t_hi) + off);
+    }
+    // candidates' cell j-1 of row r+1: substitution from m_{j-1} of row r (the base of that cell is this step's)
+    if constexpr (j >= 1)
+    {
+      const int t4[4] = { add_sext_byte<0>(mPrev, sv), add_sext_byte<1>(mPrev, sv), add_sext_byte<2>(mPrev, sv), add_sext_byte<3>(mPrev, sv) };
+      if constexpr ((j & 1) != 0)
       {
 #pragma unroll
         for (int c = 0; c < 4; c++) pend[c] = t4[c];
@@ -740,46 +842,58 @@ __device__ __forceinline__ void prk_band_fast(const int go, const int ge, const 
         for (int c = 0; c < 4; c++) bA[c] = imax3(bA[c], pend[c], t4[c]);
       }
     }
-    if (j < B)
+    if constexpr (j < B)
     {
-      const int sF = s_tab[bc * TAB_STRIDE + 4];
       const int Pm = M[j];
       int Pe = NEG;
-      if (j + 1 < B) Pe = M[j + 1] + (int)myD[((j + 1) >> 1) * (2 * BLOCK) + ((j + 1) & 1)];
+      if constexpr (j + 1 < B) Pe = M[j + 1] + dCur;
       const int sub = Pm + sF;                       // bnw_extend.c:950-956
       const int m = vmax3(sub, eC, Pe);              // max(sub, max(ins, del)), :1007-1018
       const int e = vmax3(sub + go, eC, Pe) + ge;
-      const bool better = m > bestF;                 // :1020-1024 strict >: lowest offset wins ties
-      bestF = imax(m, bestF);
-      jbest = better ? j : jbest;
       M[j] = m;
       myD[(j >> 1) * (2 * BLOCK) + (j & 1)] = (short)(e - m);
+      const int key = (int)(((unsigned)m << 4) | (unsigned)(15 - (j & 15)));
+      if constexpr ((j & 1) == 0 && j + 1 < B) kPend = key;
+      else if constexpr ((j & 1) != 0) kg[j >> 4] = imax3(kg[j >> 4], kPend, key);
+      else kg[j >> 4] = imax(kg[j >> 4], key);
       // deletion term of candidate cell j-1 is e_j (cells 1..B-1)
-      if (j >= 1)
+      if constexpr (j >= 1)
       {
-        if (j & 1) ePend = e;
+        if constexpr ((j & 1) != 0) ePend = e;
         else maxE = imax3(maxE, ePend, e);
       }
       mPrev = m;
       eC = e;
     }
-  }
+  };
+  static_for(step, std::make_integer_sequence<int, B + 1>{});
   // B is odd: the last candidate term (step B) is still pending; B-1 is even: every e has been folded
 #pragma unroll
   for (int c = 0; c < 4; c++) D.bestA[c] = imax3(bA[c], (B & 1) ? pend[c] : NEG, maxE);
-  D.bestF = bestF;
-  D.jbest = jbest;
+  // best cell: highest value, lowest group on ties (inside a group the key already prefers the lowest cell)
+  int bestv = kg[NG - 1] >> 4, bkey = kg[NG - 1], bg = NG - 1;
+#pragma unroll
+  for (int g = NG - 2; g >= 0; g--)
+  {
+    const int v = kg[g] >> 4;
+    const bool take = v >= bestv;
+    bestv = take ? v : bestv;
+    bkey = take ? kg[g] : bkey;
+    bg = take ? g : bg;
+  }
+  D.bestF = bestv;
+  D.jbest = 16 * bg + 15 - (bkey & 15);
 }
 
 template <int W, bool OOB, int BLOCK, bool INIT = false>
-__device__ __forceinline__ void prk_band(const int go, const int ge, const int *s_tab, short *sD, const int r,
+__device__ __forceinline__ void prk_band(const int go, const int ge, const int *s_tab, const FastTabs &ft, short *sD, const int r,
                                          const unsigned (&w)[(2 * W + 1 + 8) / 8 + 2], const int jlo, const int jhi,
                                          int (&M)[2 * W + 1], LaneDP &D)
 {
   constexpr int B = 2 * W + 1;
   if (!OOB && !INIT)
   {
-    prk_band_fast<W, BLOCK>(go, ge, s_tab, sD, r, w, M, D);
+    prk_band_fast<W, BLOCK>(go, ge, ft, sD, r, w, M, D);
     return;
   }
   const int edgeF = (r < W) ? go + (r + 1) * ge : SENT;
@@ -821,11 +935,23 @@ template <int W, int BLOCK>
 __global__ __launch_bounds__(BLOCK, 2) void ramx_persistent_kernel(const PArgs a)
 {
   constexpr int B = 2 * W + 1, Q = W + 1, NW = (B + 8) / 8 + 2, WPB = BLOCK / 64, RS = 2 * BLOCK;   // RS: shorts per cell-pair row of sD
-  __shared__ __attribute__((aligned(16))) int s_tab4[4][TAB_ROWS * TAB_STRIDE];   // one score table per winner base
-  __shared__ long long s_red[WPB][4];
-  __shared__ long long s_vote[4];
-  __shared__ int s_fail;
-  __shared__ short sD[((B + 1) / 2) * RS];            // d = e - m, [cell pair][thread][parity]
+  // one object, tables first: their LDS addresses must fit the 16-bit offset field of the ds_read that uses them
+  struct Smem
+  {
+    FastTabs ft;
+    int tab4[4][TAB_ROWS * TAB_STRIDE];                // one score table per winner base (masked path)
+    long long red[WPB][4];
+    long long vote[4];
+    int fail, pad[3];
+    short d[((B + 1) / 2) * RS];                       // d = e - m, [cell pair][thread][parity]
+  };
+  __shared__ __attribute__((aligned(16))) Smem sm;
+  FastTabs &s_ft = sm.ft;
+  int (&s_tab4)[4][TAB_ROWS * TAB_STRIDE] = sm.tab4;
+  long long (&s_red)[WPB][4] = sm.red;
+  long long (&s_vote)[4] = sm.vote;
+  int &s_fail = sm.fail;
+  short *sD = sm.d;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int tile = blockIdx.x * WPB + wave;
   const bool live = tile < (a.Np >> 6);
@@ -862,6 +988,8 @@ __global__ __launch_bounds__(BLOCK, 2) void ramx_persistent_kernel(const PArgs a
     if (row < RAMX_NCLASS) v = (col < 4) ? a.tab[row][col] : (col == 4 ? a.tab[row][bt] : 0);
     s_tab4[bt][e] = v;
   }
+  fast_tabs_init<BLOCK>(s_ft, a.tab);
+  __syncthreads();
 
 #ifdef RAMX_PRK_TIMING
   unsigned long long tsum[6] = { 0, 0, 0, 0, 0, 0 }, tlast = wall_clock64();
@@ -967,6 +1095,15 @@ __global__ __launch_bounds__(BLOCK, 2) void ramx_persistent_kernel(const PArgs a
         for (int k = 0; k < 4; k++)
           v[k] = wave_sum_ll((lane < a.nranks && !failed) ? (long long)(y[k] & PEER_VMASK) - PEER_VBIAS : 0LL);
       }
+      {
+        // the winner's substitution column of the fast-path tables (same argmax rule as below, ram_extend.c:1064-1086)
+        long long cw = 0;
+        int bw = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+          if (v[k] > cw) { cw = v[k]; bw = k; }
+        fast_tabs_winner(s_ft, s_tab4[bw], lane, 64);
+      }
       if (lane == 0)
       {
         s_vote[0] = v[0]; s_vote[1] = v[1]; s_vote[2] = v[2]; s_vote[3] = v[3];
@@ -1018,9 +1155,9 @@ __global__ __launch_bounds__(BLOCK, 2) void ramx_persistent_kernel(const PArgs a
       D.eC = NEG; D.mPrev = NEG - 1000000; D.bestF = NEG; D.jbest = 0;
 #pragma unroll
       for (int c = 0; c < 4; c++) { D.eA[c] = NEG; D.bestA[c] = NEG; }
-      const bool all_in = __all((jlo <= 0) && (jhi >= B));
-      if (all_in) prk_band<W, false, BLOCK>(a.go, a.ge, s_tab, sD, r, w, jlo, jhi, M, D);
-      else prk_band<W, true, BLOCK>(a.go, a.ge, s_tab, sD, r, w, jlo, jhi, M, D);
+      const bool all_in = a.pack_ok && __all((jlo <= 0) && (jhi >= B));
+      if (all_in) prk_band<W, false, BLOCK>(a.go, a.ge, s_tab, s_ft, sD, r, w, jlo, jhi, M, D);
+      else prk_band<W, true, BLOCK>(a.go, a.ge, s_tab, s_ft, sD, r, w, jlo, jhi, M, D);
       if (D.bestF > high) { high = D.bestF; pos = r + D.jbest - W; }   // ram_extend.c:1140-1150
       if (new_max) { thigh = high; tpos = pos; }                        // :1203-1207
       if (n < a.Nx)
@@ -1112,15 +1249,25 @@ struct FArgs
   signed char *cons_out;        // [family][L]
   int Np, L, go, ge, cap, minimp, when_to_stop;
   int tab[RAMX_NCLASS][4];
+  int pack_ok;
 };
 
 template <int W, int BLOCK>
 __global__ __launch_bounds__(BLOCK, 2) void ramx_family_kernel(const FArgs a)
 {
   constexpr int B = 2 * W + 1, NW = (B + 8) / 8 + 2, WPB = BLOCK / 64, RS = 2 * BLOCK;
-  __shared__ __attribute__((aligned(16))) int s_tab4[4][TAB_ROWS * TAB_STRIDE];
-  __shared__ long long s_red[2][WPB][4];
-  __shared__ short sD[((B + 1) / 2) * RS];
+  struct Smem     // tables first (16-bit ds offsets), see the persistent kernel
+  {
+    FastTabs ft;
+    int tab4[4][TAB_ROWS * TAB_STRIDE];
+    long long red[2][WPB][4];
+    short d[((B + 1) / 2) * RS];
+  };
+  __shared__ __attribute__((aligned(16))) Smem sm;
+  FastTabs &s_ft = sm.ft;
+  int (&s_tab4)[4][TAB_ROWS * TAB_STRIDE] = sm.tab4;
+  long long (&s_red)[2][WPB][4] = sm.red;
+  short *sD = sm.d;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const FamDesc fd = a.fam[blockIdx.x];
   const bool live = wave < fd.ntiles;
@@ -1134,6 +1281,7 @@ __global__ __launch_bounds__(BLOCK, 2) void ramx_family_kernel(const FArgs a)
     if (row < RAMX_NCLASS) v = (col < 4) ? a.tab[row][col] : (col == 4 ? a.tab[row][bt] : 0);
     s_tab4[bt][e] = v;
   }
+  fast_tabs_init<BLOCK>(s_ft, a.tab);
   __syncthreads();
 
   int M[B];
@@ -1178,6 +1326,12 @@ __global__ __launch_bounds__(BLOCK, 2) void ramx_family_kernel(const FArgs a)
       if (threadIdx.x == 0) a.cons_out[(size_t)blockIdx.x * a.L + r] = (signed char)besta;
     }
     const int *s_tab = s_tab4[besta];
+    if (r >= 0 && a.pack_ok)
+    {
+      // winner rows of the fast-path tables; everybody has left the previous column's band (barrier at its end)
+      fast_tabs_winner(s_ft, s_tab, threadIdx.x, BLOCK);
+      __syncthreads();
+    }
     int contrib[4] = { 0, 0, 0, 0 };
     if (live)
     {
@@ -1187,12 +1341,12 @@ __global__ __launch_bounds__(BLOCK, 2) void ramx_family_kernel(const FArgs a)
 #pragma unroll
       for (int c = 0; c < 4; c++) { D.eA[c] = NEG; D.bestA[c] = NEG; }
       if (r < 0)
-        prk_band<W, true, BLOCK, true>(a.go, a.ge, s_tab, sD, r, w, jlo, jhi, M, D);
+        prk_band<W, true, BLOCK, true>(a.go, a.ge, s_tab, s_ft, sD, r, w, jlo, jhi, M, D);
       else
       {
-        const bool all_in = __all((jlo <= 0) && (jhi >= B));
-        if (all_in) prk_band<W, false, BLOCK>(a.go, a.ge, s_tab, sD, r, w, jlo, jhi, M, D);
-        else prk_band<W, true, BLOCK>(a.go, a.ge, s_tab, sD, r, w, jlo, jhi, M, D);
+        const bool all_in = a.pack_ok && __all((jlo <= 0) && (jhi >= B));
+        if (all_in) prk_band<W, false, BLOCK>(a.go, a.ge, s_tab, s_ft, sD, r, w, jlo, jhi, M, D);
+        else prk_band<W, true, BLOCK>(a.go, a.ge, s_tab, s_ft, sD, r, w, jlo, jhi, M, D);
         if (D.bestF > high) { high = D.bestF; pos = r + D.jbest - W; }
         if (new_max) { thigh = high; tpos = pos; }
       }
@@ -1529,6 +1683,24 @@ extern "C" int ramx_dev_peer_enable(ramx_dev *d, int on)
   return RAMX_OK;
 }
 
+// The fast band packs (score << 4 | cell) keys: exact while every reachable |score| < 2^27 (a row-r cell is at most
+// (r + W + 2) steps of at most max(|matrix|, |go| + |ge|) away from 0), and reads matrix entries as int8.  Scoring
+// systems outside these bounds take the general (masked-path) band for every wave.
+static int fast_pack_ok(const int (&tab)[RAMX_NCLASS][4], int go, int ge, int L, int W)
+{
+  long long mx = (long long)(go < 0 ? -go : go) + (long long)(ge < 0 ? -ge : ge);
+  for (int c = 0; c < RAMX_NCLASS; c++)
+    for (int k = 0; k < 4; k++)
+    {
+      const long long v = tab[c][k] < 0 ? -(long long)tab[c][k] : (long long)tab[c][k];
+      if (v > mx) mx = v;
+    }
+  for (int c = 0; c < RAMX_NCLASS; c++)
+    for (int k = 0; k < 4; k++)
+      if (tab[c][k] < -128 || tab[c][k] > 127) return 0;       // the fast tables hold the candidates' scores as int8
+  return ((long long)L + 2LL * W + 4) * mx < (1LL << 27) ? 1 : 0;
+}
+
 // ---- persistent path --------------------------------------------------------------------------
 // Block shape of the persistent launch: at most ONE barrier participant per CU.
 //   <= 4 tiles per CU (N <= 65,536): 256-thread blocks, one wave per SIMD, up to 256 blocks;
@@ -1609,6 +1781,7 @@ static int prk_run(ramx_dev *d, const KArgs &a, int L, bool *used)
     if ((rc = host_allreduce_shards(d, d->d_sums)) != RAMX_OK) return rc;     // vote of row 0 (from K(-1)) over ranks
   }
   memcpy(pa.tab, a.tab, sizeof(pa.tab));
+  pa.pack_ok = getenv("RAMX_NO_FASTPACK") ? 0 : fast_pack_ok(pa.tab, a.go, a.ge, L, W);
   HIPCHK(hipMemsetAsync(d->d_vote, 0, 3 * NSHARD * sizeof(PShard), d->stream));
   HIPCHK(hipMemsetAsync(d->d_err, 0, 64, d->stream));
   *used = true;
@@ -1713,6 +1886,7 @@ extern "C" int ramx_dev_run_families(ramx_dev *d, const ramx_flank *flanks, int3
     const int code = (c == 8) ? RAMX_SYM_N : c;
     for (int k = 0; k < 4; k++) fa.tab[c][k] = p->matrix[k * 100 + code];
   }
+  fa.pack_ok = getenv("RAMX_NO_FASTPACK") ? 0 : fast_pack_ok(fa.tab, fa.go, fa.ge, L, W);
   HIPCHK(hipEventRecord(d->ev_begin, d->stream));
   if (maxn <= 256)
     rc = (W == 14) ? fam_launch<14, 256>(d, fa, n_families) : (W == 20) ? fam_launch<20, 256>(d, fa, n_families) : fam_launch<40, 256>(d, fa, n_families);

@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B on ONE box: every ab_tmp/libramx_*.so is copied over the package's library and timed on the same points.
-# usage: NS="65536 100000" WS="40" bash tools/ab_libs.sh
+# usage: NS="65536 100000" WS="40" [BATCH=1] bash tools/ab_libs.sh
 cp repeatafterme_amd/libramx.so /tmp/libramx_keep.so
 for rep in 1 2; do
 for lib in ab_tmp/libramx_*.so; do
@@ -15,6 +15,7 @@ print('$lib', 'N', $n, 'W', $w, 'us/col', round(r['us_per_column'],2))
 "
     done
   done
+  if [ -n "$BATCH" ]; then echo "$lib $(python tools/bench_batch.py 500 2>&1 | head -1)"; fi
 done
 done
 cp /tmp/libramx_keep.so repeatafterme_amd/libramx.so
