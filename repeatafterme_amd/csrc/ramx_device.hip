@@ -708,17 +708,17 @@ __device__ __forceinline__ void static_for(F &&f, std::integer_sequence<int, Js.
   (f(std::integral_constant<int, Js>{}), ...);
 }
 
-// Score tables of the in-bounds fast path, addressed straight from the packed base stream with ONE SDWA instruction:
-// the eight nibbles of an aligned base word sit in four bytes; for the high nibble of byte n the LDS byte offset is
-// (byte & 0xF0) (16-byte rows indexed by class), for the low nibble it is (byte << 4) into a 256-row table whose row
-// depends on the low nibble only.  A row is {M[A][b] | M[C][b] | M[G][b] | M[T][b] as four int8, M[besta][b], -, -}:
-// one ds_read_b64 per cell; the candidates' scores are consumed by sign-extending SDWA adds.  Dword 1 is rewritten
-// for every column (the winner changes), by wave 0 / before a block barrier.  Requires every score in [-128, 127]
-// (checked on the host together with the key-packing bound).
+// Score table of the in-bounds fast path, addressed straight from the packed base stream with ONE SDWA instruction:
+// the eight nibbles of an aligned base word sit in four bytes; the LDS byte offset of the row of a class is
+// (byte & 0xF0) for the high nibble and (byte << 4) for the low nibble of a word whose high nibbles have been cleared
+// (one v_and per eight cells).  16 rows of 16 bytes: lanes reading the same class broadcast, different classes sit in
+// different banks.  A row is {M[A][b] | M[C][b] | M[G][b] | M[T][b] as four int8, M[besta][b], -, -}: one ds_read_b64
+// per cell; the candidates' scores are consumed by sign-extending SDWA adds.  Dword 1 is rewritten for every column
+// (the winner changes), by wave 0 / before a block barrier.  Requires every score in [-128, 127] (checked on the
+// host together with the key-packing bound).
 struct FastTabs
 {
-  int lo[256][4];
-  int hi[16][4];
+  int row[16][4];
 };
 
 template <int BYTE>
@@ -757,26 +757,20 @@ __device__ __forceinline__ int add_sext_byte(int x, int packed)   // x + (int)(s
 template <int BLOCK>
 __device__ __forceinline__ void fast_tabs_init(FastTabs &ft, const int (&tab)[RAMX_NCLASS][4])
 {
-  for (int i = threadIdx.x; i < 256 + 16; i += BLOCK)
+  if (threadIdx.x < 16)
   {
-    const int cls = i < 256 ? (i & 15) : (i - 256);
+    const int cls = threadIdx.x;
     unsigned pk = 0;
     if (cls < RAMX_NCLASS)
       pk = ((unsigned)tab[cls][0] & 0xffu) | (((unsigned)tab[cls][1] & 0xffu) << 8) | (((unsigned)tab[cls][2] & 0xffu) << 16) |
            (((unsigned)tab[cls][3] & 0xffu) << 24);
-    int *row = i < 256 ? ft.lo[i] : ft.hi[i - 256];
-    row[0] = (int)pk; row[1] = 0; row[2] = 0; row[3] = 0;
+    ft.row[cls][0] = (int)pk; ft.row[cls][1] = 0; ft.row[cls][2] = 0; ft.row[cls][3] = 0;
   }
 }
-// winner dword of the column whose winner is `besta`: rows i, i + nthreads, ... of the 256 (+16) by thread i.
-__device__ __forceinline__ void fast_tabs_winner(FastTabs &ft, const int *tab_besta /* old-format table of besta */, int i, int nthreads)
+// winner dword of the column whose winner is `besta` (threads 0..15 of the caller's group)
+__device__ __forceinline__ void fast_tabs_winner(FastTabs &ft, const int *tab_besta /* old-format table of besta */, int i)
 {
-  for (int row = i; row < 256; row += nthreads)
-  {
-    const int cls = row & 15;
-    ft.lo[row][1] = cls < RAMX_NCLASS ? tab_besta[cls * TAB_STRIDE + 4] : 0;
-  }
-  if (i < 16) ft.hi[i][1] = i < RAMX_NCLASS ? tab_besta[i * TAB_STRIDE + 4] : 0;
+  if (i < 16) ft.row[i][1] = i < RAMX_NCLASS ? tab_besta[i * TAB_STRIDE + 4] : 0;
 }
 
 // In-bounds, chain-free band of the register-resident kernels (the steady state of a run): per cell
@@ -792,7 +786,7 @@ __device__ __forceinline__ void prk_band_fast(const int go, const int ge, const 
   const int ph4 = 4 * ((r + 8) & 7);
   const unsigned mask_f0 = 0xf0u;
   short *myD = sD + 2 * threadIdx.x;
-  const char *t_lo = reinterpret_cast<const char *>(&ft.lo[0][0]), *t_hi = reinterpret_cast<const char *>(&ft.hi[0][0]);
+  const char *tb = reinterpret_cast<const char *>(&ft.row[0][0]);
   int eC = NEG, mPrev = NEG, maxE = NEG, ePend = NEG, kPend = NEG;
   int bA[4] = { NEG, NEG, NEG, NEG }, pend[4] = { NEG, NEG, NEG, NEG };
   int kg[NG];
@@ -801,7 +795,8 @@ __device__ __forceinline__ void prk_band_fast(const int go, const int ge, const 
   // compile-time cell index: the band is generated step by step (no reliance on the loop unroller, whose size limit
   // would otherwise leave the row in scratch memory).  Table rows are fetched one step ahead of their use.
   unsigned A = __builtin_amdgcn_alignbit(w[1], w[0], ph4);
-  int2 rowN = *reinterpret_cast<const int2 *>(t_lo + nib_lo_x16<0>(A));      // {candidate bytes, M[besta][base]}
+  unsigned Alo = A & 0x0f0f0f0fu;                   // low nibbles only: (byte << 4) is then the row offset of the class
+  int2 rowN = *reinterpret_cast<const int2 *>(tb + nib_lo_x16<0>(Alo));      // {candidate bytes, M[besta][base]}
   int dN = (B > 1) ? (int)myD[1] : 0;               // e - m of the previous row's cell j+1, fetched one step ahead too
   auto step = [&](auto jc) __attribute__((always_inline))
   {
@@ -819,13 +814,17 @@ __device__ __forceinline__ void prk_band_fast(const int go, const int ge, const 
     if constexpr (j + 1 <= B)
     {
       constexpr int jn = j + 1;
-      if constexpr ((jn & 7) == 0) A = __builtin_amdgcn_alignbit(w[(jn >> 3) + 1], w[jn >> 3], ph4);
+      if constexpr ((jn & 7) == 0)
+      {
+        A = __builtin_amdgcn_alignbit(w[(jn >> 3) + 1], w[jn >> 3], ph4);
+        Alo = A & 0x0f0f0f0fu;
+      }
       constexpr bool lo = (jn & 1) == 0;
       constexpr int byte = (jn & 7) / 2;
       unsigned off;
-      if constexpr (lo) off = nib_lo_x16<byte>(A);
+      if constexpr (lo) off = nib_lo_x16<byte>(Alo);
       else off = nib_hi_x16<byte>(A, mask_f0);
-      rowN = *reinterpret_cast<const int2 *>((lo ? t_lo : t_hi) + off);
+      rowN = *reinterpret_cast<const int2 *>(tb + off);
     }
     // candidates' cell j-1 of row r+1: substitution from m_{j-1} of row r (the base of that cell is this step's)
     if constexpr (j >= 1)
@@ -1102,7 +1101,7 @@ __global__ __launch_bounds__(BLOCK, 2) void ramx_persistent_kernel(const PArgs a
 #pragma unroll
         for (int k = 0; k < 4; k++)
           if (v[k] > cw) { cw = v[k]; bw = k; }
-        fast_tabs_winner(s_ft, s_tab4[bw], lane, 64);
+        fast_tabs_winner(s_ft, s_tab4[bw], lane);
       }
       if (lane == 0)
       {
@@ -1329,7 +1328,7 @@ __global__ __launch_bounds__(BLOCK, 2) void ramx_family_kernel(const FArgs a)
     if (r >= 0 && a.pack_ok)
     {
       // winner rows of the fast-path tables; everybody has left the previous column's band (barrier at its end)
-      fast_tabs_winner(s_ft, s_tab, threadIdx.x, BLOCK);
+      fast_tabs_winner(s_ft, s_tab, threadIdx.x);
       __syncthreads();
     }
     int contrib[4] = { 0, 0, 0, 0 };
@@ -1817,6 +1816,14 @@ static int prk_run(ramx_dev *d, const KArgs &a, int L, bool *used)
       fprintf(stderr, "PRK_TIMING %-18s wave0 avg %8.1f  other waves avg %8.1f  min %8.1f  max %8.1f\n", nm[k], s0 / blocks,
               wpb > 1 ? sO / (double)(nw - blocks) : 0.0, mn, mx);
     }
+    fprintf(stderr, "PRK_TIMING band by wave index:");
+    for (int wv = 0; wv < wpb; wv++)
+    {
+      double sw = 0;
+      for (int b = 0; b < blocks - 1; b++) sw += 10.0 * (double)h[((size_t)b * wpb + wv) * 8 + 2] / L;
+      fprintf(stderr, " w%d %.0f", wv, sw / (blocks > 1 ? blocks - 1 : 1));
+    }
+    fprintf(stderr, "\n");
     free(h);
     (void)hipFree(pa.dbg);
   }

@@ -99,3 +99,42 @@ def test_too_many_flanks_for_residency_fall_back_to_streaming():
     b = gpu_extend(1, c2, fs.sequence, m2, p)
     assert b.persistent == 0
     assert a.ret == b.ret and np.array_equal(m1, m2) and np.array_equal(c1.right_len, c2.right_len) and np.array_equal(c1.score, c2.score)
+
+
+def _scaled(p, k):
+    """The same scoring system with every score multiplied by k (a valid user-supplied matrix for the C-ABI)."""
+    q = po.Params(**{f: getattr(p, f) for f in ("bandwidth", "cappenalty", "minimprovement", "L", "when_to_stop", "l",
+                                                  "gapopen", "gapextn", "matrix")})
+    m = q.matrix.astype(np.int64).copy().reshape(100, 100)
+    for a in range(4):
+        for b in list(range(8)) + [99]:
+            m[a, b] *= k
+    q.matrix = m.reshape(-1).astype(np.int32)
+    q.gapopen *= k; q.gapextn *= k; q.cappenalty *= k; q.minimprovement *= k
+    return q
+
+
+@pytest.mark.parametrize("W", [14, 40])
+def test_fast_band_bounds_and_fallback(W, monkeypatch):
+    """The in-bounds fast band packs (score << 4 | cell) keys and reads int8 scores; scoring systems outside those
+    bounds must take the general band for every wave (host check), and the switch RAMX_NO_FASTPACK forces it."""
+    fs = synth_family(700, 200, W, K=150, seed=77, both_sides=True, minus_frac=0.3, n_run_frac=0.2)
+    base = po.Params.named("14p43g", bandwidth=W, L=200, when_to_stop=40)
+    ref = run_both_directions(oracle_extend, fs.cores, fs.sequence, base)
+    for env in (None, "1"):
+        if env is None:
+            monkeypatch.delenv("RAMX_NO_FASTPACK", raising=False)
+        else:
+            monkeypatch.setenv("RAMX_NO_FASTPACK", env)
+        got = run_both_directions(gpu_extend, fs.cores, fs.sequence, base)
+        assert_same_result(ref[0], ref[1], ref[2:], got[0], got[1], got[2:], f"NO_FASTPACK={env}")
+        assert got[2].persistent == 1
+    monkeypatch.delenv("RAMX_NO_FASTPACK", raising=False)
+    for k in (5, 20, 900):           # 5: still int8; 20: scores leave int8; 900: go + ge leaves int16 (streaming kernel)
+        p = _scaled(base, k)
+        a = run_both_directions(oracle_extend, fs.cores, fs.sequence, p)
+        b = run_both_directions(gpu_extend, fs.cores, fs.sequence, p)
+        assert_same_result(a[0], a[1], a[2:], b[0], b[1], b[2:], f"scale={k}")
+        assert b[2].persistent == (1 if k < 900 else 0)
+        # scaling every score scales nothing else: same consensus and lengths as the unscaled run
+        assert np.array_equal(a[1], ref[1]) and np.array_equal(a[0].left_len, ref[0].left_len)
