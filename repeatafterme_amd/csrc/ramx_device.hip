@@ -363,11 +363,11 @@ __device__ __forceinline__ void band_step(const int go, const int ge, const int 
 
 // The whole band of one flank (one lane) for column r: streams S(r-1) in, S(r) out.
 template <bool INIT, bool OOB, bool CHAIN>
-__device__ __forceinline__ void run_band(const KArgs &a, const int *s_tab, const int4 *Sin, int4 *Sout,
+__device__ __forceinline__ void run_band(const KArgs &a, const int r, const int *s_tab, const int4 *Sin, int4 *Sout,
                                          const unsigned *bp, const int jlo, const int jhi, LaneDP &D, int &high, int &pos,
                                          int4 (&buf)[PF], int4 (&far)[PF], unsigned w0, unsigned w1, unsigned w2)
 {
-  const int W = a.W, B = 2 * W + 1, Q = W + 1, go = a.go, ge = a.ge, r = a.r;
+  const int W = a.W, B = 2 * W + 1, Q = W + 1, go = a.go, ge = a.ge;
   // OOB fill values (bnw_extend.c:990-1002): uniform per (row, cell)
   const int edgeF = (r < W) ? go + (r + 1) * ge : SENT;        // row r,   cells j < W
   const int edgeC = (r + 1 < W) ? go + (r + 2) * ge : SENT;    // row r+1, cells j-1 < W
@@ -585,8 +585,8 @@ __global__ __launch_bounds__(BLOCK) void ramx_column_kernel(const KArgs a)
     int high = 0, pos = 0;
     // wave-uniform choice: do all 64 flanks cover every cell of both rows?  (steps 0..B)
     const bool all_in = !INIT && __all((jlo <= 0) && (jhi >= B));
-    if (all_in) run_band<INIT, false, CHAIN>(a, s_tab, Sin, Sout, bp, jlo, jhi, D, high, pos, buf, far, w0, w1, w2);
-    else run_band<INIT, true, CHAIN>(a, s_tab, Sin, Sout, bp, jlo, jhi, D, high, pos, buf, far, w0, w1, w2);
+    if (all_in) run_band<INIT, false, CHAIN>(a, r, s_tab, Sin, Sout, bp, jlo, jhi, D, high, pos, buf, far, w0, w1, w2);
+    else run_band<INIT, true, CHAIN>(a, r, s_tab, Sin, Sout, bp, jlo, jhi, D, high, pos, buf, far, w0, w1, w2);
     if (INIT || new_max) a.trim[n] = make_int2(high, pos);   // ram_extend.c:1203-1207 (913-914 at init)
     if (n < a.Nx)
     {
@@ -1382,6 +1382,135 @@ __global__ __launch_bounds__(BLOCK, 2) void ramx_family_kernel(const FArgs a)
   }
 }
 
+// Batch mode for everything the register-resident family kernel cannot take (any band width, positive penalties):
+// the same one-workgroup-per-family loop with a block-local vote, but the rows stream through the family's slice of
+// the in-place row buffer exactly as in ramx_column_kernel (run_band: runtime W, prefetch rings, CHAIN variant).  A
+// lane only ever reads state it wrote itself, so no cross-lane visibility is needed between columns; a family's rows
+// (W = 80, 100 flanks: 260 KB) stay in L2.
+struct FSArgs
+{
+  KArgs k;                      // bases, bounds, trim, S_in == S_out, Np, W, go, ge, cap, minimp, when_to_stop, tab
+  const FamDesc *fam;
+  RamxCtl *ctl_out;             // per family
+  signed char *cons_out;        // [family][L]
+  int L;
+};
+
+template <bool CHAIN, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void ramx_family_stream_kernel(const FSArgs fa)
+{
+  constexpr int WPB = BLOCK / 64;
+  __shared__ __attribute__((aligned(16))) int s_tab[TAB_ROWS * TAB_STRIDE];
+  __shared__ long long s_red[2][WPB][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const FamDesc fd = fa.fam[blockIdx.x];
+  const bool live = wave < fd.ntiles;
+  const int tile = fd.tile0 + (live ? wave : 0);
+  const int n = tile * 64 + lane;
+  const bool active = live && (wave * 64 + lane) < fd.nx;
+  const KArgs &a = fa.k;
+  const int W = a.W, B = 2 * W + 1, Q = W + 1;
+  const int4 *Sin = a.S_in + (size_t)tile * Q * 64 + lane;
+  int4 *Sout = a.S_out + (size_t)tile * Q * 64 + lane;
+  const int2 bd = a.bounds[n];
+  long long max_ext = 0;
+  int max_row = -1, rows_done = 0, ovf = 0, stopped = 0;
+
+  for (int r = -1; r < fa.L; r++)
+  {
+    const unsigned *bp = a.bases + (size_t)((r + 8) >> 3) * a.Np + n;
+    int4 buf[PF], far[PF];
+    if (r >= 0)
+    {
+#pragma unroll
+      for (int i = 0; i < PF; i++) buf[i] = ld_stream(Sin + (size_t)(i < Q ? i : Q - 1) * 64);
+#pragma unroll
+      for (int i = 0; i < PF; i++) far[i] = ld_stream(Sin + (size_t)(i + PF < Q ? i + PF : Q - 1) * 64);
+    }
+    const unsigned w0 = bp[0], w1 = bp[(size_t)a.Np], w2 = bp[2 * (size_t)a.Np];
+    int besta = 0;
+    bool new_max = false;
+    if (r >= 0)
+    {
+      long long curr = 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+      {
+        long long vk = 0;
+#pragma unroll
+        for (int wv = 0; wv < WPB; wv++) vk += s_red[r & 1][wv][k];
+        if (vk > 2147483647LL || vk < -2147483648LL) ovf = 1;
+        if (vk > curr) { curr = vk; besta = k; }
+      }
+      int dist = max_row - r;
+      dist = dist < 0 ? -dist : dist;
+      new_max = curr >= max_ext + (long long)dist * a.minimp;
+      if (new_max) { max_row = r; max_ext = curr; }
+      int d2 = r - max_row;
+      d2 = d2 < 0 ? -d2 : d2;
+      stopped = d2 >= a.when_to_stop;
+      rows_done = r + 1;
+      if (threadIdx.x == 0) fa.cons_out[(size_t)blockIdx.x * fa.L + r] = (signed char)besta;
+    }
+    // the winner's score table; everybody has left the previous column's band (barrier at its end)
+    if (threadIdx.x < TAB_ROWS * TAB_STRIDE)
+    {
+      const int row = threadIdx.x / TAB_STRIDE, col = threadIdx.x % TAB_STRIDE;
+      int v = 0;
+      if (row < RAMX_NCLASS) v = (col < 4) ? a.tab[row][col] : (col == 4 ? a.tab[row][besta] : 0);
+      s_tab[threadIdx.x] = v;
+    }
+    __syncthreads();
+    int contrib[4] = { 0, 0, 0, 0 };
+    if (live)
+    {
+      const int jlo = bd.x - r, jhi = bd.y - r;
+      LaneDP D;
+      D.eC = NEG; D.mPrev = NEG - 1000000; D.bestF = NEG; D.jbest = 0;
+#pragma unroll
+      for (int c = 0; c < 4; c++) { D.eA[c] = NEG; D.bestA[c] = NEG; }
+      int high = 0, pos = 0;
+      if (r < 0)
+        run_band<true, true, CHAIN>(a, r, s_tab, Sin, Sout, bp, jlo, jhi, D, high, pos, buf, far, w0, w1, w2);
+      else
+      {
+        const bool all_in = __all((jlo <= 0) && (jhi >= B));
+        if (all_in) run_band<false, false, CHAIN>(a, r, s_tab, Sin, Sout, bp, jlo, jhi, D, high, pos, buf, far, w0, w1, w2);
+        else run_band<false, true, CHAIN>(a, r, s_tab, Sin, Sout, bp, jlo, jhi, D, high, pos, buf, far, w0, w1, w2);
+      }
+      if (r < 0 || new_max) a.trim[n] = make_int2(high, pos);
+      if (active)
+      {
+        const int capv = high + a.cap;
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+        {
+          const int b = D.bestA[c] < 0 ? 0 : D.bestA[c];
+          contrib[c] = (b >= capv) ? b : capv;
+        }
+      }
+    }
+    if (stopped || r == fa.L - 1) break;
+    {
+      long long tot[4];
+#pragma unroll
+      for (int c = 0; c < 4; c++) tot[c] = wave_sum_nonneg31(contrib[c]);
+      if (lane == 0)
+      {
+#pragma unroll
+        for (int c = 0; c < 4; c++) s_red[(r + 1) & 1][wave][c] = tot[c];
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0)
+  {
+    RamxCtl o;
+    o.max_ext = max_ext; o.max_row = max_row; o.stopped = stopped; o.rows_done = rows_done; o.overflow = ovf; o.besta = 0; o.pad = 0;
+    fa.ctl_out[blockIdx.x] = o;
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // host side of seam 2
 // ------------------------------------------------------------------------------------------
@@ -1848,8 +1977,10 @@ extern "C" int ramx_dev_run_families(ramx_dev *d, const ramx_flank *flanks, int3
   { ramx_set_error("ramx_dev_run_families: bad argument"); return RAMX_ERR_ARG; }
   HIPCHK(hipSetDevice(d->ordinal));
   const int W = p->bandwidth, L = p->L;
-  if (!prk_has_width(W) || p->gapopen > 0 || p->gapextn > 0 || p->gapopen + p->gapextn < -32768 || L < 0)
-  { ramx_set_error("batch mode needs bandwidth 14/20/40 and non-positive gap penalties"); return RAMX_ERR_UNSUPPORTED; }
+  if (W < 1 || L < 0) { ramx_set_error("ramx_dev_run_families: bad bandwidth / L"); return RAMX_ERR_ARG; }
+  // register-resident family kernel where it applies, the streaming family kernel for everything else
+  const bool resident = prk_has_width(W) && p->gapopen <= 0 && p->gapextn <= 0 && p->gapopen + p->gapextn >= -32768 &&
+                        !d->force_chain && getenv("RAMX_NO_PERSISTENT") == NULL;
   int maxn = 0;
   for (int f = 0; f < n_families; f++)
   {
@@ -1895,7 +2026,37 @@ extern "C" int ramx_dev_run_families(ramx_dev *d, const ramx_flank *flanks, int3
   }
   fa.pack_ok = getenv("RAMX_NO_FASTPACK") ? 0 : fast_pack_ok(fa.tab, fa.go, fa.ge, L, W);
   HIPCHK(hipEventRecord(d->ev_begin, d->stream));
-  if (maxn <= 256)
+  if (!resident)
+  {
+    // rows of every family in the (in-place) row buffer: 16 B x (W + 1) slots per flank
+    const size_t state_bytes = (size_t)Np * (W + 1) * sizeof(int4);
+    if (state_bytes > d->cap_state || !d->d_state[0])
+    {
+      if (d->d_state[0]) HIPCHK(hipFree(d->d_state[0]));
+      if (d->d_state[1] && d->d_state[1] != d->d_state[0]) HIPCHK(hipFree(d->d_state[1]));
+      d->d_state[0] = d->d_state[1] = NULL;
+      HIPCHK(hipMalloc((void **)&d->d_state[0], state_bytes));
+      d->d_state[1] = d->d_state[0];
+      d->cap_state = state_bytes;
+    }
+    FSArgs fs;
+    memset(&fs, 0, sizeof(fs));
+    fs.k.bases = d->d_bases; fs.k.bounds = d->d_bounds; fs.k.trim = d->d_trim; fs.k.S_in = d->d_state[0]; fs.k.S_out = d->d_state[0];
+    fs.k.Np = Np; fs.k.Nx = Np; fs.k.W = W; fs.k.go = p->gapopen; fs.k.ge = p->gapextn; fs.k.cap = p->cappenalty;
+    fs.k.minimp = p->minimprovement; fs.k.when_to_stop = p->when_to_stop;
+    memcpy(fs.k.tab, fa.tab, sizeof(fs.k.tab));
+    fs.fam = dfd; fs.ctl_out = dctl; fs.cons_out = d->d_cons; fs.L = L;
+    const bool chain = p->gapopen > 0 || p->gapextn > 0 || d->force_chain;
+    const int blk = maxn <= 64 ? 64 : maxn <= 128 ? 128 : maxn <= 256 ? 256 : 512;
+#define RAMX_FS_LAUNCH(CH, BL) hipLaunchKernelGGL((ramx_family_stream_kernel<CH, BL>), dim3(n_families), dim3(BL), 0, d->stream, fs)
+    if (chain) { if (blk == 64) RAMX_FS_LAUNCH(true, 64); else if (blk == 128) RAMX_FS_LAUNCH(true, 128); else if (blk == 256) RAMX_FS_LAUNCH(true, 256); else RAMX_FS_LAUNCH(true, 512); }
+    else { if (blk == 64) RAMX_FS_LAUNCH(false, 64); else if (blk == 128) RAMX_FS_LAUNCH(false, 128); else if (blk == 256) RAMX_FS_LAUNCH(false, 256); else RAMX_FS_LAUNCH(false, 512); }
+#undef RAMX_FS_LAUNCH
+    hipError_t le = hipGetLastError();
+    if (le != hipSuccess) { free(hfd); ramx_set_error("family stream kernel launch: %s", hipGetErrorString(le)); return RAMX_ERR_HIP; }
+    rc = RAMX_OK;
+  }
+  else if (maxn <= 256)
     rc = (W == 14) ? fam_launch<14, 256>(d, fa, n_families) : (W == 20) ? fam_launch<20, 256>(d, fa, n_families) : fam_launch<40, 256>(d, fa, n_families);
   else
     rc = (W == 14) ? fam_launch<14, 512>(d, fa, n_families) : (W == 20) ? fam_launch<20, 512>(d, fa, n_families) : fam_launch<40, 512>(d, fa, n_families);
@@ -1924,7 +2085,7 @@ extern "C" int ramx_dev_run_families(ramx_dev *d, const ramx_flank *flanks, int3
     infos[f].n_extendable = fam_count[f];
     infos[f].launches = 1;
     infos[f].loop_ms = ms;
-    infos[f].persistent = 1;
+    infos[f].persistent = resident ? 1 : 2;     /* 2: streaming family kernel */
   }
   free(hctl); free(hfd);
   (void)hipFree(dfd); (void)hipFree(dctl);

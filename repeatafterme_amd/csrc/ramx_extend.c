@@ -257,7 +257,9 @@ int ramx_extend_batch(int direction, ramx_family *fam, int32_t F, const ramx_par
   const int W = p->bandwidth, L = p->L;
   int rc = RAMX_OK;
   /* which families can the batch kernel take? */
-  int batchable = (W == 14 || W == 20 || W == 40) && p->gapopen <= 0 && p->gapextn <= 0 && p->gapopen + p->gapextn >= -32768;
+  /* every band width and gap sign has a family kernel (register-resident for W = 14/20/40 with non-positive
+   * penalties, streaming otherwise); only families above one workgroup (512 flanks) go one by one */
+  int batchable = W >= 1 && L >= 0;
   uint64_t total_len = 0;
   size_t total_pad = 0;
   int *take = (int *)calloc((size_t)(F ? F : 1), sizeof(int));

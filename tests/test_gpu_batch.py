@@ -67,3 +67,31 @@ def test_batch_edge_cases_and_fallback():
             o = po.oracle_extend(1, c, f.sequence, m, p)
             assert infos[i].ret == o.ret and infos[i].rows_executed == o.rows_executed, (W, i)
             assert np.array_equal(ms[i], m) and np.array_equal(cs[i].right_len, c.right_len) and np.array_equal(cs[i].score, c.score)
+
+
+@pytest.mark.parametrize("W,matrix,kw", [
+    (80, "20p43g", {}),                                  # BASELINE config 5: wide band
+    (9, "14p43g", {}),                                   # a width with no register-resident instantiation
+    (33, "repeatscout", dict(gap=-2)),
+    (40, "14p43g", dict(gapopen=3, gapextn=-4)),         # positive penalty: full candidate recurrence (CHAIN)
+    (14, "25p43g", dict(gapopen=-20, gapextn=2)),
+])
+def test_streaming_family_kernel_any_width_and_gap_sign(W, matrix, kw):
+    """Families the register-resident batch kernel cannot take run in the streaming family kernel (persistent == 2):
+    still one launch for all of them, each equal to its own oracle run."""
+    fams = _families(24)
+    p = po.Params.named(matrix, bandwidth=W, L=160, when_to_stop=25, **kw)
+    got_c = [fs.cores.copy() for fs in fams]
+    got_m = [new_master(p.L) for _ in fams]
+    ep = to_extend_params(p)
+    ir = extend_batch(1, [(c, fs.sequence, m) for c, fs, m in zip(got_c, fams, got_m)], ep)
+    il = extend_batch(0, [(c, fs.sequence, m) for c, fs, m in zip(got_c, fams, got_m)], ep)
+    for i, fs in enumerate(fams):
+        c = fs.cores.copy(); m = new_master(p.L)
+        r1 = po.oracle_extend(1, c, fs.sequence, m, p)
+        r0 = po.oracle_extend(0, c, fs.sequence, m, p)
+        assert (ir[i].ret, il[i].ret, ir[i].rows_executed, il[i].rows_executed) == (r1.ret, r0.ret, r1.rows_executed, r0.rows_executed), (W, i)
+        assert np.array_equal(got_m[i], m), (W, i)
+        assert np.array_equal(got_c[i].left_len, c.left_len) and np.array_equal(got_c[i].right_len, c.right_len), (W, i)
+        assert np.array_equal(got_c[i].score, c.score), (W, i)
+        assert ir[i].persistent == 2 and il[i].persistent == 2

@@ -43,7 +43,7 @@ def _read(path):
 @pytest.mark.parametrize("bandwidth,matrix,extra", [
     (40, "14p43g", ["-vvv", "-minimprovement", "30"]),        # the wrapper's configuration: batch kernel
     (14, "25p43g", ["-stopafter", "20"]),                     # batch kernel, quiet
-    (7, "20p43g", ["-vvv"]),                                  # width without a batch kernel: one-by-one inside
+    (7, "20p43g", ["-vvv"]),                                  # width without a register-resident kernel: streaming family kernel
     (20, "repeatscout", ["-vvv", "-addflanking", "5"]),
 ])
 def test_batch_cli_equals_reference_per_family(bandwidth, matrix, extra, tmp_path):

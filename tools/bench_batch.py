@@ -7,8 +7,8 @@ from repeatafterme_amd.extend import extend_alignment, extend_batch
 from repeatafterme_amd.scoring import named_params
 from repeatafterme_amd.synth import synth_family
 
-F, W, L = int(sys.argv[1]) if len(sys.argv) > 1 else 500, 40, 1200
-p = named_params("14p43g", bandwidth=W, L=L)
+F, W, L = int(sys.argv[1]) if len(sys.argv) > 1 else 500, int(sys.argv[2]) if len(sys.argv) > 2 else 40, 1200
+p = named_params("14p43g" if W != 80 else "20p43g", bandwidth=W, L=L)
 fams = [synth_family(int(60 + (i * 37) % 90), L, W, K=300 + (i * 53) % 500, seed=1000 + i) for i in range(F)]
 cols = None
 for rep in range(2):
