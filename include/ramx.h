@@ -198,16 +198,17 @@ int ramx_dev_peek_state(ramx_dev *d, int32_t flank, int32_t *cells, int32_t *hig
 /* Batch mode (no counterpart in the reference, whose wrapper util/extend-stk.pl:242-371 starts one
  * RAMExtend process per family): many families in ONE launch, one workgroup per family, every family with its own
  * consensus / vote / stop rule.  Flanks are family-major; every family starts at a multiple of 64 in the flank
- * array (pad with empty flanks: t_lo = 1, t_hi = 0) and has at most 512 flanks; bandwidth 14, 20 or 40 and
- * non-positive gap penalties (else RAMX_ERR_UNSUPPORTED: run those families one by one through seam 1).
+ * array (pad with empty flanks: t_lo = 1, t_hi = 0) and has at most 512 flanks (else RAMX_ERR_UNSUPPORTED: run such
+ * a family through seam 1).  Band widths 14, 20 and 40 with non-positive gap penalties keep the rows in registers
+ * (infos[].persistent == 1); every other band width / gap sign streams them through L2 (persistent == 2).
  * cons is [n_families][L]; trim_* are per (padded) flank; infos per family.  The library must be loaded first. */
 int ramx_dev_run_families(ramx_dev *d, const ramx_flank *flanks, int32_t n_padded, const int32_t *fam_first,
                           const int32_t *fam_count, int32_t n_families, const ramx_params *p,
                           ramx_run_info *infos, int8_t *cons, int32_t *trim_high, int32_t *trim_pos);
 
 /* The same on the reference-like flat data model: family f = cores[f] on its own library sequence[f]; master[f] and
- * the cores' extension lengths / scores are updated exactly as ramx_extend_flat does for one family.  Families the
- * batch kernel cannot take are run one by one.  Returns 0 or a negative error code; infos[f].ret is the per-family
+ * the cores' extension lengths / scores are updated exactly as ramx_extend_flat does for one family.  Families with
+ * more than 512 extendable cores are run one by one.  Returns 0 or a negative error code; infos[f].ret is the per-family
  * return value of extend_alignment. */
 typedef struct ramx_family
 {
