@@ -16,8 +16,12 @@
  *   - bases are upper-cased, A,C,G,T -> 0..3, everything else (N blocks) -> 99.
  */
 #include <ctype.h>
+#include <pthread.h>
 #include <stdlib.h>
+#include <unistd.h>
+#include <stdio.h>
 #include <string.h>
+#include <time.h>
 
 #include "ramx_internal.h"
 
@@ -145,31 +149,101 @@ static void tb_select(struct tb_file *t, const char *name)
   t->cur = ix;
 }
 
-/* decode [start,end) of the selected record straight into reference base codes */
-static void tb_read_codes(struct tb_file *t, const char *name, int start, int end, char *out)
+struct nblocks { uint32_t count; uint32_t *start, *size; struct nblocks *next_alloc; };
+
+struct window
 {
-  static const char val_to_code[4] = { 3, 1, 0, 2 };   /* 2bit: T=0 C=1 A=2 G=3 (kentsrc/dnautil.h:23-27) */
-  tb_select(t, name);
-  if ((uint32_t)end > t->size) die255("twoBitReadSeqFrag in %s end (%ld) >= seqSize (%ld)", name, end, t->size);
-  if (end - start < 1) die255("twoBitReadSeqFrag in %s start (%ld) >= end (%ld)", name, start, end);
+  int flank_start, flank_end, lower_flank_len;
+  enum CoreBoundFlag lower_flag, upper_flag;
+  uint64_t dna_offset;              /* file offset of the packed DNA of the window's record */
+  const struct nblocks *nb;         /* N blocks of that record (shared by the windows of the record) */
+};
+
+/* decode [start,end) of a record straight into reference base codes.  Thread-safe: pread on the descriptor, a
+ * 256-entry table turns one packed byte into four codes (2bit: T=0 C=1 A=2 G=3, kentsrc/dnautil.h:23-27). */
+static uint32_t g_quad[256];
+static void quad_init(void)
+{
+  static const unsigned char val_to_code[4] = { 3, 1, 0, 2 };
+  for (int b = 0; b < 256; b++)
+  {
+    unsigned char q[4];
+    for (int k = 0; k < 4; k++) q[k] = val_to_code[(b >> (6 - 2 * k)) & 3];
+    memcpy(&g_quad[b], q, 4);
+  }
+}
+
+static int tb_decode(int fd, const char *path, uint64_t dna_offset, const struct nblocks *nb, int start, int end, char *out,
+                     unsigned char **scratch, size_t *scratch_cap)
+{
   const int p0 = start >> 2, p1 = (end + 3) >> 2;
-  unsigned char *packed = (unsigned char *)malloc((size_t)(p1 - p0));
-  fseeko(t->f, (off_t)(t->dna_offset + (uint64_t)p0), SEEK_SET);
-  if (fread(packed, 1, (size_t)(p1 - p0), t->f) != (size_t)(p1 - p0)) die255("%s is truncated", t->path, 0, 0);
-  for (int i = start; i < end; i++)
+  const size_t nbytes = (size_t)(p1 - p0);
+  if (nbytes > *scratch_cap)
+  {
+    free(*scratch);
+    *scratch_cap = nbytes + (nbytes >> 2) + 64;
+    *scratch = (unsigned char *)malloc(*scratch_cap);
+  }
+  unsigned char *packed = *scratch;
+  size_t got = 0;
+  while (got < nbytes)
+  {
+    ssize_t k = pread(fd, packed + got, nbytes - got, (off_t)(dna_offset + (uint64_t)p0 + got));
+    if (k <= 0) return -1;
+    got += (size_t)k;
+  }
+  (void)path;
+  int i = start;
+  /* head: up to the next multiple of four */
+  for (; i < end && (i & 3); i++)
   {
     const unsigned char b = packed[(i >> 2) - p0];
-    out[i - start] = val_to_code[(b >> (6 - 2 * (i & 3))) & 3];
+    out[i - start] = (char)((g_quad[b] >> (8 * (i & 3))) & 0xff);
   }
-  free(packed);
-  for (uint32_t k = 0; k < t->n_count; k++)
+  /* body: four bases per table lookup */
+  for (; i + 4 <= end; i += 4)
   {
-    long s = t->n_start[k], e = s + t->n_size[k];
-    if (s >= end) break;
-    if (s < start) s = start;
-    if (e > end) e = end;
-    if (s < e) memset(out + (s - start), RAMX_SYM_N, (size_t)(e - s));
+    const uint32_t q = g_quad[packed[(i >> 2) - p0]];
+    memcpy(out + (i - start), &q, 4);
   }
+  for (; i < end; i++)
+  {
+    const unsigned char b = packed[(i >> 2) - p0];
+    out[i - start] = (char)((g_quad[b] >> (8 * (i & 3))) & 0xff);
+  }
+  for (uint32_t k = 0; k < nb->count; k++)
+  {
+    long s0 = nb->start[k], e0 = s0 + nb->size[k];
+    if (s0 >= end) break;
+    if (s0 < start) s0 = start;
+    if (e0 > end) e0 = end;
+    if (s0 < e0) memset(out + (s0 - start), RAMX_SYM_N, (size_t)(e0 - s0));
+  }
+  return 0;
+}
+
+struct decode_job
+{
+  int fd;
+  const char *path;
+  const struct window *win;
+  const uint64_t *at;               /* start of window i in lib->sequence */
+  char *sequence;
+  int lo, hi;                       /* windows [lo, hi) */
+  int failed;
+};
+
+static void *decode_worker(void *arg)
+{
+  struct decode_job *j = (struct decode_job *)arg;
+  unsigned char *scratch = NULL;
+  size_t cap = 0;
+  for (int i = j->lo; i < j->hi && !j->failed; i++)
+    if (tb_decode(j->fd, j->path, j->win[i].dna_offset, j->win[i].nb, j->win[i].flank_start, j->win[i].flank_end,
+                  j->sequence + j->at[i], &scratch, &cap) != 0)
+      j->failed = 1;
+  free(scratch);
+  return NULL;
 }
 
 /* ------------------------------------------------------------------ BED-6 ranges */
@@ -264,11 +338,6 @@ static void sort_ranges(struct range **v, struct range **tmp, int n)
   memcpy(v, tmp, sizeof(*v) * (size_t)n);
 }
 
-struct window
-{
-  int flank_start, flank_end, lower_flank_len;
-  enum CoreBoundFlag lower_flag, upper_flag;
-};
 
 /* flank clipping for one range: sequence.c:546-743 */
 static void plan_window(const struct range *s, const struct range *prev, const struct range *next,
@@ -350,25 +419,56 @@ static void plan_window(const struct range *s, const struct range *prev, const s
   }
 }
 
+static double ld_now(void)
+{
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec * 1e3 + 1e-6 * (double)ts.tv_nsec;
+}
+#define LD_PHASE(name) do { if (timing) { const double t_ = ld_now(); fprintf(stderr, "RAMX_TIMING   loader: %-14s %9.3f ms\n", name, t_ - t_last); t_last = t_; } } while (0)
+
 struct sequenceLibrary *ramx_load_sequence_subset_minimal(const char *twoBitName, const char *rangeBEDName,
                                                           struct coreAlignment **core_align, int *num_cores,
                                                           int max_flanking_bp)
 {
+  const int timing = getenv("RAMX_TIMING") != NULL;
+  double t_last = timing ? ld_now() : 0;
   int n = 0;
   struct range *ranges = read_ranges(rangeBEDName, &n);
+  LD_PHASE("read ranges");
   struct tb_file *tb = tb_open(twoBitName);
+  LD_PHASE("2bit index");
   struct range **order = (struct range **)malloc(sizeof(*order) * (size_t)(n ? n : 1));
   struct range **tmp = (struct range **)malloc(sizeof(*tmp) * (size_t)(n ? n : 1));
   for (int i = 0; i < n; i++) order[i] = &ranges[i];
   sort_ranges(order, tmp, n);
   free(tmp);
+  LD_PHASE("sort");
 
   struct window *win = (struct window *)malloc(sizeof(*win) * (size_t)(n ? n : 1));
+  uint64_t *at_of = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)(n ? n : 1));
+  struct nblocks *nb_list = NULL;
+  const struct tb_index *nb_for = NULL;
   uint64_t total = 0;
   for (int i = 0; i < n; i++)
   {
     const struct range *s = order[i];
     tb_select(tb, s->name);
+    if (nb_for != tb->cur)          /* the N blocks of this record, kept for the decoding threads */
+    {
+      struct nblocks *nb = (struct nblocks *)malloc(sizeof(*nb));
+      nb->count = tb->n_count;
+      nb->start = (uint32_t *)malloc(sizeof(uint32_t) * (tb->n_count ? tb->n_count : 1));
+      nb->size = (uint32_t *)malloc(sizeof(uint32_t) * (tb->n_count ? tb->n_count : 1));
+      memcpy(nb->start, tb->n_start, sizeof(uint32_t) * tb->n_count);
+      memcpy(nb->size, tb->n_size, sizeof(uint32_t) * tb->n_count);
+      nb->next_alloc = nb_list;
+      nb_list = nb;
+      nb_for = tb->cur;
+    }
+    win[i].dna_offset = tb->dna_offset;
+    win[i].nb = nb_list;
+    at_of[i] = total;
     plan_window(s, i ? order[i - 1] : NULL, i + 1 < n ? order[i + 1] : NULL, (int)tb->size, max_flanking_bp, &win[i]);
     if ((uint32_t)win[i].flank_end > tb->size)
       die255("twoBitReadSeqFrag in %s end (%ld) >= seqSize (%ld)", s->name, win[i].flank_end, tb->size);
@@ -377,18 +477,57 @@ struct sequenceLibrary *ramx_load_sequence_subset_minimal(const char *twoBitName
     total += (uint64_t)(win[i].flank_end - win[i].flank_start);
   }
 
+  LD_PHASE("plan windows");
   struct sequenceLibrary *lib = (struct sequenceLibrary *)calloc(1, sizeof(*lib));
   lib->sequence = (char *)malloc(total + 1);
   lib->identifiers = (char **)calloc((size_t)n + 1, sizeof(char *));
   lib->boundaries = (uint64_t *)calloc((size_t)n + 1, sizeof(uint64_t));
   lib->offsets = (uint64_t *)calloc((size_t)n + 1, sizeof(uint64_t));
   struct coreAlignment *cores = (struct coreAlignment *)calloc((size_t)(n ? n : 1), sizeof(*cores));
+  /* decode every window: independent reads (pread) and writes, split over the host cores by bases */
+  {
+    quad_init();
+    int nthreads = 1;
+    const char *env = getenv("RAMX_LOADER_THREADS");
+    if (env) nthreads = atoi(env);
+    else if (total >= (8u << 20))
+    {
+      long c = sysconf(_SC_NPROCESSORS_ONLN);
+      nthreads = c > 16 ? 16 : (int)c;
+    }
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > n) nthreads = n > 0 ? n : 1;
+    struct decode_job *jobs = (struct decode_job *)calloc((size_t)nthreads, sizeof(*jobs));
+    pthread_t *tid = (pthread_t *)calloc((size_t)nthreads, sizeof(*tid));
+    int lo = 0;
+    for (int t = 0; t < nthreads; t++)
+    {
+      /* windows up to the t+1-th share of the bases */
+      const uint64_t goal = total / (uint64_t)nthreads * (uint64_t)(t + 1);
+      int hi = lo;
+      while (hi < n && (t == nthreads - 1 || at_of[hi] < goal)) hi++;
+      jobs[t].fd = fileno(tb->f); jobs[t].path = tb->path; jobs[t].win = win; jobs[t].at = at_of;
+      jobs[t].sequence = lib->sequence; jobs[t].lo = lo; jobs[t].hi = hi; jobs[t].failed = 0;
+      lo = hi;
+    }
+    for (int t = 1; t < nthreads; t++)
+      if (pthread_create(&tid[t], NULL, decode_worker, &jobs[t]) != 0) { decode_worker(&jobs[t]); tid[t] = 0; }
+    decode_worker(&jobs[0]);
+    int failed = jobs[0].failed;
+    for (int t = 1; t < nthreads; t++)
+    {
+      if (tid[t]) pthread_join(tid[t], NULL);
+      failed |= jobs[t].failed;
+    }
+    free(jobs); free(tid);
+    if (failed) die255("%s is truncated", tb->path, 0, 0);
+  }
+  LD_PHASE("decode");
   uint64_t at = 0;
   for (int i = 0; i < n; i++)
   {
     const struct range *s = order[i];
     const uint64_t size = (uint64_t)(win[i].flank_end - win[i].flank_start);
-    tb_read_codes(tb, s->name, win[i].flank_start, win[i].flank_end, lib->sequence + at);
     lib->identifiers[i] = dupstr(s->name);
     lib->boundaries[i] = at + size;                 /* cumulative end, 0-terminated list */
     lib->offsets[i] = (uint64_t)win[i].flank_start;
@@ -422,7 +561,9 @@ struct sequenceLibrary *ramx_load_sequence_subset_minimal(const char *twoBitName
   *num_cores = n;
 
   for (int i = 0; i < n; i++) { free(ranges[i].name); free(ranges[i].left_flag); free(ranges[i].right_flag); free(ranges[i].strand); }
-  free(ranges); free(order); free(win);
+  LD_PHASE("cores");
+  free(ranges); free(order); free(win); free(at_of);
+  while (nb_list) { struct nblocks *nx = nb_list->next_alloc; free(nb_list->start); free(nb_list->size); free(nb_list); nb_list = nx; }
   tb_close(tb);
   return lib;
 }

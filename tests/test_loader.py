@@ -53,7 +53,9 @@ def test_loader_matches_reference_table(case, stem, maxflank):
 @pytest.mark.skipif(not po.have_ref(), reason="oracle/_ref not built here")
 @pytest.mark.parametrize("stem,maxflank", [("extension-test2", 10014), ("genome_0", 60), ("genome_1", 314), ("genome_2", 2000),
                                            ("genome_3", 5), ("genome_ov", 150)])
-def test_loader_vs_reference_loader_live(stem, maxflank):
+@pytest.mark.parametrize("threads", ["1", "5"])
+def test_loader_vs_reference_loader_live(stem, maxflank, threads, monkeypatch):
+    monkeypatch.setenv("RAMX_LOADER_THREADS", threads)       # the decoding threads split the windows by bases
     ref = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libramref.so"))
     ref.loadSequenceSubsetMinimal.restype = C.POINTER(_SeqLib)
     ref.loadSequenceSubsetMinimal.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.POINTER(_Core)), C.POINTER(C.c_int), C.c_int]
