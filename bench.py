@@ -142,7 +142,7 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
             return int(t.item())
         if os.environ.get("RAMX_NO_PEER") is None:
-            peer_path = dev.peer_setup(rank, world, ag_bytes, ar_min, dist.barrier)   # vote over xGMI from inside the kernel
+            peer_path = dev.peer_setup(rank, world, ag_bytes, ar_min, dist.barrier)   # vote exchanged from inside the kernel
     t0 = time.time()
     dev.load_library(fs.sequence)
     flanks, idx = resolve_flanks(1, fs.cores, W, L)
@@ -209,7 +209,9 @@ def main():
                                f"K=1500 @14% divergence, right extension, stopafter=L (all L columns)",
                    "flanks_total": total_flanks, "columns_per_step": cols // max(args.steps, 1),
                    "parallelism": (f"flank-sharded x{world}, per-column vote "
-                                   + ("exchanged over xGMI inside the persistent kernels (peer mailboxes)" if (peer_path and persistent)
+                                   + (("exchanged inside the persistent kernels (mailboxes in "
+                                       + ("peer device memory over xGMI)" if getattr(dev, "peer_kind", None) == "device"
+                                          else "registered host shared memory over PCIe)")) if (peer_path and persistent)
                                       else "all-reduced with RCCL between column launches")) if world > 1 else "single GPU"},
         "columns_per_sec": cols / dt,
         "cell_updates_per_sec": cols / dt * total_flanks * (2 * W + 1) * 4,

@@ -235,6 +235,14 @@ int ramx_dev_peer_import(ramx_dev *d, const uint8_t *handles /* [nranks][64] */,
 int ramx_dev_peer_selftest(ramx_dev *d, int phase, unsigned long long token);
 int ramx_dev_peer_enable(ramx_dev *d, int on);
 
+/* Host-memory variant of the same mailboxes (second choice when the device-memory boxes cannot be mapped into the
+ * other processes or fail their self-test): every rank's box lives in one POSIX shared-memory segment that each
+ * process registers with HIP; the kernels' system-scope stores and polls then cross PCIe.  All ranks of the node
+ * call attach with the same name, run the self-test of ramx_dev_peer_selftest and ramx_dev_peer_enable as above;
+ * afterwards rank 0 may unlink the name. */
+int ramx_dev_hostbox_attach(ramx_dev *d, const char *shm_name, int rank, int nranks);
+int ramx_hostbox_unlink(const char *shm_name);
+
 /* test hook: replaces RCCL by a caller-supplied all-reduce so the sharded control flow (fold kernel, reduced
  * vote consumed by the next column, replicated stop rule) can be exercised where RCCL cannot run, e.g. two
  * ranks sharing the single GPU of a test box.  cb must sum 4 int64 in place across ranks and block until

@@ -15,7 +15,7 @@ EXPORTS = [
     "ramx_dev_create", "ramx_dev_destroy", "ramx_dev_load_library", "ramx_dev_begin_direction",
     "ramx_dev_run_direction", "ramx_dev_download", "ramx_dev_peek_state", "ramx_dev_run_families", "ramx_extend_batch", "ramx_comm_unique_id",
     "ramx_dev_comm_init", "ramx_dev_set_allreduce_cb", "ramx_dev_peer_export", "ramx_dev_peer_import",
-    "ramx_dev_peer_selftest", "ramx_dev_peer_enable", "ramx_get_matrix", "ramx_get_matrix_using_gap_penalties",
+    "ramx_dev_peer_selftest", "ramx_dev_peer_enable", "ramx_dev_hostbox_attach", "ramx_hostbox_unlink", "ramx_get_matrix", "ramx_get_matrix_using_gap_penalties",
     "ramx_get_repeatscout_matrix", "ramx_free_scoring_system", "ramx_calculate_lambda",
     "ramx_load_sequence_subset_minimal", "ramx_free_library", "ramx_overlap_avoidance",
     "ramx_print_core_edges", "ramx_allocate_score", "ramx_free_score", "ramx_cli_main",
@@ -99,6 +99,8 @@ def lib() -> C.CDLL:
         L.ramx_dev_peer_import.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         L.ramx_dev_peer_selftest.argtypes = [C.c_void_p, C.c_int, C.c_uint64]
         L.ramx_dev_peer_enable.argtypes = [C.c_void_p, C.c_int]
+        L.ramx_dev_hostbox_attach.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int]
+        L.ramx_hostbox_unlink.argtypes = [C.c_char_p]
         if hasattr(L, "ramx_cli_main"):
             L.ramx_cli_main.argtypes = [C.c_int, C.POINTER(C.c_char_p)]
         _lib = L

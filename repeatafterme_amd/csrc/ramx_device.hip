@@ -35,6 +35,10 @@
 #include <hip/hip_runtime.h>
 #include <utility>
 #include <rccl/rccl.h>
+#include <errno.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <unistd.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -1536,6 +1540,9 @@ struct ramx_dev
   ramx_allreduce_cb cb; void *cb_user;
   // cross-device persistent path: this rank's box (fine-grained), every rank's box as mapped here, device copy of that table
   PeerBox *xbox; PeerBox *peer[RAMX_MAX_RANKS]; PeerBox **d_peer; int peer_ready;
+  // host-memory variant of the boxes (POSIX shared memory registered with HIP): xbox/peer point into it
+  void *hostbox_map; size_t hostbox_bytes; PeerBox *hostbox_host; int hostbox_registered;
+  PeerBox *devbox;     // this rank's fine-grained device-memory box (exported over hipIpc)
   int force_chain;   // RAMX_FORCE_CHAIN=1: always run the full candidate recurrence (test hook)
 };
 
@@ -1589,6 +1596,13 @@ extern "C" void ramx_dev_destroy(ramx_dev *d)
   (void)hipFree(d->d_state[0]); if (d->d_state[1] != d->d_state[0]) (void)hipFree(d->d_state[1]); (void)hipFree(d->d_trim); (void)hipFree(d->d_sums);
   (void)hipFree(d->d_ctl); (void)hipFree(d->d_cons); (void)hipFree(d->d_vote); (void)hipFree(d->d_err);
   (void)hipHostFree(d->h_ctl);
+  if (d->hostbox_map)
+  {
+    if (d->hostbox_registered) (void)hipHostUnregister(d->hostbox_map);
+    munmap(d->hostbox_map, d->hostbox_bytes);
+  }
+  if (d->devbox) (void)hipFree(d->devbox);
+  if (d->d_peer) (void)hipFree(d->d_peer);
   for (int i = 0; i < 2; i++) (void)hipEventDestroy(d->ev_chk[i]);
   (void)hipEventDestroy(d->ev_begin); (void)hipEventDestroy(d->ev_end);
   for (int i = 0; i < MAX_SAMPLES; i++) { (void)hipEventDestroy(d->ev_s0[i]); (void)hipEventDestroy(d->ev_s1[i]); }
@@ -1736,14 +1750,14 @@ extern "C" int ramx_dev_peer_export(ramx_dev *d, uint8_t handle[64])
 {
   if (!d || !handle) { ramx_set_error("ramx_dev_peer_export: bad argument"); return RAMX_ERR_ARG; }
   HIPCHK(hipSetDevice(d->ordinal));
-  if (!d->xbox)
+  if (!d->devbox)
   {
-    hipError_t e = hipExtMallocWithFlags((void **)&d->xbox, sizeof(PeerBox), hipDeviceMallocFinegrained);
-    if (e != hipSuccess) { d->xbox = NULL; ramx_set_error("fine-grained allocation for the peer box failed: %s", hipGetErrorString(e)); return RAMX_ERR_HIP; }
-    HIPCHK(hipMemset(d->xbox, 0, sizeof(PeerBox)));
+    hipError_t e = hipExtMallocWithFlags((void **)&d->devbox, sizeof(PeerBox), hipDeviceMallocFinegrained);
+    if (e != hipSuccess) { d->devbox = NULL; ramx_set_error("fine-grained allocation for the peer box failed: %s", hipGetErrorString(e)); return RAMX_ERR_HIP; }
+    HIPCHK(hipMemset(d->devbox, 0, sizeof(PeerBox)));
   }
   hipIpcMemHandle_t h;
-  HIPCHK(hipIpcGetMemHandle(&h, d->xbox));
+  HIPCHK(hipIpcGetMemHandle(&h, d->devbox));
   static_assert(sizeof(hipIpcMemHandle_t) <= 64, "ipc handle size");
   memset(handle, 0, 64);
   memcpy(handle, &h, sizeof(h));
@@ -1758,11 +1772,12 @@ __global__ void ramx_peer_token_kernel(PeerBox *const *peers, int rank, int nran
 
 extern "C" int ramx_dev_peer_import(ramx_dev *d, const uint8_t *handles, int rank, int nranks)
 {
-  if (!d || !handles || rank < 0 || rank >= nranks || nranks > RAMX_MAX_RANKS || !d->xbox)
+  if (!d || !handles || rank < 0 || rank >= nranks || nranks > RAMX_MAX_RANKS || !d->devbox)
   { ramx_set_error("ramx_dev_peer_import: bad argument (export first; at most %d ranks)", RAMX_MAX_RANKS); return RAMX_ERR_ARG; }
   HIPCHK(hipSetDevice(d->ordinal));
   d->peer_ready = 0;
   d->rank = rank; d->nranks = nranks;
+  d->xbox = d->devbox; d->hostbox_host = NULL;
   for (int q = 0; q < nranks; q++)
   {
     if (q == rank) { d->peer[q] = d->xbox; continue; }
@@ -1776,6 +1791,47 @@ extern "C" int ramx_dev_peer_import(ramx_dev *d, const uint8_t *handles, int ran
   if (!d->d_peer) HIPCHK(hipMalloc((void **)&d->d_peer, RAMX_MAX_RANKS * sizeof(PeerBox *)));
   HIPCHK(hipMemcpy(d->d_peer, d->peer, nranks * sizeof(PeerBox *), hipMemcpyHostToDevice));
   return RAMX_OK;
+}
+
+/* Host-memory mailboxes: the same PeerBox protocol with every rank's box in ONE POSIX shared-memory segment that each
+ * process registers with HIP (hipHostRegisterMapped).  Stores and polls cross PCIe instead of xGMI; no IPC handles,
+ * no peer access between devices needed.  Used when the device-memory boxes cannot be mapped or fail their
+ * self-test.  Every rank calls attach with the same name (ranks of one node); after a barrier rank 0 may unlink. */
+extern "C" int ramx_dev_hostbox_attach(ramx_dev *d, const char *shm_name, int rank, int nranks)
+{
+  if (!d || !shm_name || rank < 0 || rank >= nranks || nranks > RAMX_MAX_RANKS)
+  { ramx_set_error("ramx_dev_hostbox_attach: bad argument (at most %d ranks)", RAMX_MAX_RANKS); return RAMX_ERR_ARG; }
+  HIPCHK(hipSetDevice(d->ordinal));
+  d->peer_ready = 0;
+  const size_t bytes = (((size_t)nranks * sizeof(PeerBox)) + 4095) & ~(size_t)4095;
+  int fd = shm_open(shm_name, O_CREAT | O_RDWR, 0600);
+  if (fd < 0) { ramx_set_error("shm_open(%s): %s", shm_name, strerror(errno)); return RAMX_ERR_COMM; }
+  if (ftruncate(fd, (off_t)bytes) != 0) { ramx_set_error("ftruncate(%s): %s", shm_name, strerror(errno)); close(fd); return RAMX_ERR_COMM; }
+  void *map = mmap(NULL, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  close(fd);
+  if (map == MAP_FAILED) { ramx_set_error("mmap(%s): %s", shm_name, strerror(errno)); return RAMX_ERR_COMM; }
+  hipError_t e = hipHostRegister(map, bytes, hipHostRegisterMapped | hipHostRegisterPortable);
+  if (e != hipSuccess) { munmap(map, bytes); ramx_set_error("hipHostRegister(shared boxes): %s", hipGetErrorString(e)); return RAMX_ERR_HIP; }
+  void *dptr = NULL;
+  e = hipHostGetDevicePointer(&dptr, map, 0);
+  if (e != hipSuccess) { (void)hipHostUnregister(map); munmap(map, bytes); ramx_set_error("hipHostGetDevicePointer: %s", hipGetErrorString(e)); return RAMX_ERR_HIP; }
+  if (d->hostbox_map) { if (d->hostbox_registered) (void)hipHostUnregister(d->hostbox_map); munmap(d->hostbox_map, d->hostbox_bytes); }
+  d->hostbox_map = map; d->hostbox_bytes = bytes; d->hostbox_registered = 1;
+  d->hostbox_host = (PeerBox *)map + rank;
+  memset(d->hostbox_host, 0, sizeof(PeerBox));          // my own box; the others clear theirs
+  d->rank = rank; d->nranks = nranks;
+  // the device-memory box (if any) is no longer the exchange target
+  d->xbox = (PeerBox *)dptr + rank;
+  for (int q = 0; q < nranks; q++) d->peer[q] = (PeerBox *)dptr + q;
+  if (!d->d_peer) HIPCHK(hipMalloc((void **)&d->d_peer, RAMX_MAX_RANKS * sizeof(PeerBox *)));
+  HIPCHK(hipMemcpy(d->d_peer, d->peer, nranks * sizeof(PeerBox *), hipMemcpyHostToDevice));
+  return RAMX_OK;
+}
+
+extern "C" int ramx_hostbox_unlink(const char *shm_name)
+{
+  if (!shm_name) return RAMX_ERR_ARG;
+  return shm_unlink(shm_name) == 0 ? RAMX_OK : RAMX_ERR_COMM;
 }
 
 /* self-test of the mapped boxes: write a token into every rank's box, then (after the caller has synchronised the
@@ -1794,7 +1850,8 @@ extern "C" int ramx_dev_peer_selftest(ramx_dev *d, int phase, unsigned long long
   PeerBox h;
   for (int tries = 0; tries < 200; tries++)
   {
-    HIPCHK(hipMemcpy(&h, d->xbox, sizeof(h), hipMemcpyDeviceToHost));
+    if (d->hostbox_host) memcpy(&h, (const void *)d->hostbox_host, sizeof(h));
+    else HIPCHK(hipMemcpy(&h, d->xbox, sizeof(h), hipMemcpyDeviceToHost));
     int ok = 1;
     for (int q = 0; q < d->nranks; q++) ok &= (h.token[q] == token);
     if (ok) return 1;
@@ -1905,7 +1962,13 @@ static int prk_run(ramx_dev *d, const KArgs &a, int L, bool *used)
     pa.nranks = d->nranks; pa.rank = d->rank; pa.peers = (PeerBox *const *)d->d_peer; pa.box = d->xbox;
     // my box is cleared BEFORE the collective below, which no remote launch can get past without my taking part:
     // nobody writes a word of this run into it too early, and nothing of the last run survives
-    HIPCHK(hipMemsetAsync(d->xbox, 0, sizeof(PeerBox), d->stream));
+    if (d->hostbox_host)
+    {
+      HIPCHK(hipStreamSynchronize(d->stream));
+      memset((void *)d->hostbox_host, 0, sizeof(PeerBox));
+      __sync_synchronize();
+    }
+    else HIPCHK(hipMemsetAsync(d->xbox, 0, sizeof(PeerBox), d->stream));
     if ((rc = host_allreduce_shards(d, d->d_sums)) != RAMX_OK) return rc;     // vote of row 0 (from K(-1)) over ranks
   }
   memcpy(pa.tab, a.tab, sizeof(pa.tab));

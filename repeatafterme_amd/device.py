@@ -98,25 +98,55 @@ class Device:
         _lib.check(self._L.ramx_dev_set_allreduce_cb(self._h, self._cb, None), "ramx_dev_set_allreduce_cb")
 
     def peer_setup(self, rank: int, world: int, all_gather_bytes, all_reduce_min, barrier) -> bool:
-        """Cross-device persistent path (ramx_dev_peer_*): exchange the mailbox IPC handles, self-test, enable the
-        path only if it works on every rank.  all_gather_bytes(bytes64) -> list of world bytes objects;
-        all_reduce_min(int) -> int; barrier() -> None.  Returns whether the path is enabled."""
-        ok = 1
-        h = np.zeros(64, np.uint8)
-        if self._L.ramx_dev_peer_export(self._h, h.ctypes.data) < 0:
-            ok = 0
-        handles = all_gather_bytes(h.tobytes())
-        if all_reduce_min(ok) == 1:
-            allh = np.frombuffer(b"".join(handles), np.uint8).copy()
-            if self._L.ramx_dev_peer_import(self._h, allh.ctypes.data, rank, world) < 0:
+        """In-kernel vote exchange for the cross-device persistent path.  Two tiers, each enabled only if it works on
+        every rank (self-test), tried in this order:
+          "device": every rank's mailbox in fine-grained device memory, mapped into the others over hipIpc (xGMI);
+          "host":   the mailboxes in one POSIX shared-memory segment registered with HIP (PCIe; ranks of one node).
+        RAMX_PEER_KIND=device|host restricts the choice (tests).  all_gather_bytes(bytes64) -> list of world bytes
+        objects; all_reduce_min(int) -> int; barrier() -> None.  Returns whether a tier is enabled; `peer_kind` names
+        it ("device", "host" or None)."""
+        import os
+        only = os.environ.get("RAMX_PEER_KIND", "")
+        token = 0x52414D58000000 + world
+        self.peer_kind = None
+
+        def selftest(ok):
+            if all_reduce_min(ok) == 1:
+                if self._L.ramx_dev_peer_selftest(self._h, 0, token) < 0:
+                    ok = 0
+                barrier()
+                if ok and self._L.ramx_dev_peer_selftest(self._h, 1, token) != 1:
+                    ok = 0
+            return all_reduce_min(ok)
+
+        if only in ("", "device"):
+            ok = 1
+            h = np.zeros(64, np.uint8)
+            if self._L.ramx_dev_peer_export(self._h, h.ctypes.data) < 0:
                 ok = 0
-        if all_reduce_min(ok) == 1:
-            token = 0x52414D58000000 + world
-            if self._L.ramx_dev_peer_selftest(self._h, 0, token) < 0:
-                ok = 0
-            barrier()
-            if ok and self._L.ramx_dev_peer_selftest(self._h, 1, token) != 1:
-                ok = 0
-        ok = all_reduce_min(ok)
-        self._L.ramx_dev_peer_enable(self._h, int(ok == 1))
-        return ok == 1
+            handles = all_gather_bytes(h.tobytes())
+            if all_reduce_min(ok) == 1:
+                allh = np.frombuffer(b"".join(handles), np.uint8).copy()
+                if self._L.ramx_dev_peer_import(self._h, allh.ctypes.data, rank, world) < 0:
+                    ok = 0
+            if selftest(ok) == 1:
+                self._L.ramx_dev_peer_enable(self._h, 1)
+                self.peer_kind = "device"
+                return True
+        if only in ("", "host"):
+            # one name for the job: rank 0's pid, spread through the same all-gather
+            mine = np.zeros(64, np.uint8)
+            tag = (b"/ramx_box_%d" % os.getpid())[:63]
+            mine[:len(tag)] = np.frombuffer(tag, np.uint8)
+            name = bytes(all_gather_bytes(mine.tobytes())[0]).split(b"\0", 1)[0]
+            ok = 1 if self._L.ramx_dev_hostbox_attach(self._h, name, rank, world) >= 0 else 0
+            barrier()                       # every box exists and has been cleared by its owner
+            ok = selftest(ok)
+            if rank == 0:
+                self._L.ramx_hostbox_unlink(name)
+            if ok == 1:
+                self._L.ramx_dev_peer_enable(self._h, 1)
+                self.peer_kind = "host"
+                return True
+        self._L.ramx_dev_peer_enable(self._h, 0)
+        return False

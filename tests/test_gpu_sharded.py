@@ -21,7 +21,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out, peer=False, W=20):
+def _worker(rank, world, port, out, peer=False, W=20, kind=""):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -59,7 +59,10 @@ def _worker(rank, world, port, out, peer=False, W=20):
 
         def ar_min(v):
             t = torch.tensor([v]); dist.all_reduce(t, op=dist.ReduceOp.MIN); return int(t.item())
+        if kind:
+            os.environ["RAMX_PEER_KIND"] = kind
         enabled = dev.peer_setup(rank, world, ag_bytes, ar_min, dist.barrier)
+        enabled = enabled and (not kind or dev.peer_kind == kind)
     else:
         os.environ["RAMX_NO_PERSISTENT"] = "1"          # per-column launches + host collective
     dev.load_library(fs.sequence)
@@ -92,17 +95,18 @@ def test_two_ranks_one_gpu_equal_single_process_oracle():
         assert used == 0
 
 
-@pytest.mark.parametrize("W", [14, 40])
-def test_two_ranks_cross_device_persistent_path(W):
-    """Same two ranks, but with the peer mailboxes (hipIpc-mapped fine-grained memory) enabled: each rank runs ONE
-    persistent launch per direction and the per-column vote is exchanged from inside the kernels (system-scope
-    stores into every rank's box).  The two cooperative launches share the test box's single GPU."""
+@pytest.mark.parametrize("W,kind", [(14, "device"), (40, "device"), (20, "host"), (40, "host"), (40, "")])
+def test_two_ranks_cross_device_persistent_path(W, kind):
+    """Same two ranks, but with the mailboxes enabled: each rank runs ONE persistent launch per direction and the
+    per-column vote is exchanged from inside the kernels (system-scope stores into every rank's box).  kind "device":
+    fine-grained device memory mapped over hipIpc; "host": one POSIX shared-memory segment registered with HIP; "":
+    the production order (device first).  The two cooperative launches share the test box's single GPU."""
     from oracle import pyoracle as po
     from repeatafterme_amd.datamodel import new_master
     from repeatafterme_amd.synth import synth_family
     world = 2
     out = mp.Manager().dict()
-    mp.spawn(_worker, args=(world, _free_port(), out, True, W), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), out, True, W, kind), nprocs=world, join=True)
     fs = synth_family(333, 150, W, K=100, seed=12, both_sides=True, minus_frac=0.3, n_run_frac=0.1)
     p = po.Params.named("14p43g", bandwidth=W, L=150, when_to_stop=25)
     c = fs.cores.copy(); m = new_master(p.L)
