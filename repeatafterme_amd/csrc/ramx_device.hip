@@ -1457,12 +1457,12 @@ __global__ __launch_bounds__(BLOCK) void ramx_family_stream_kernel(const FSArgs 
       if (threadIdx.x == 0) fa.cons_out[(size_t)blockIdx.x * fa.L + r] = (signed char)besta;
     }
     // the winner's score table; everybody has left the previous column's band (barrier at its end)
-    if (threadIdx.x < TAB_ROWS * TAB_STRIDE)
+    for (int i = threadIdx.x; i < TAB_ROWS * TAB_STRIDE; i += BLOCK)      // BLOCK may be 64: fewer threads than entries
     {
-      const int row = threadIdx.x / TAB_STRIDE, col = threadIdx.x % TAB_STRIDE;
+      const int row = i / TAB_STRIDE, col = i % TAB_STRIDE;
       int v = 0;
       if (row < RAMX_NCLASS) v = (col < 4) ? a.tab[row][col] : (col == 4 ? a.tab[row][besta] : 0);
-      s_tab[threadIdx.x] = v;
+      s_tab[i] = v;
     }
     __syncthreads();
     int contrib[4] = { 0, 0, 0, 0 };

@@ -95,3 +95,26 @@ def test_streaming_family_kernel_any_width_and_gap_sign(W, matrix, kw):
         assert np.array_equal(got_c[i].left_len, c.left_len) and np.array_equal(got_c[i].right_len, c.right_len), (W, i)
         assert np.array_equal(got_c[i].score, c.score), (W, i)
         assert ir[i].persistent == 2 and il[i].persistent == 2
+
+
+@pytest.mark.parametrize("maxn", [20, 64, 100, 200, 400])
+def test_streaming_family_kernel_block_sizes(maxn):
+    """The streaming family kernel is launched with 64, 128, 256 or 512 threads depending on the largest family of
+    the batch; every shape must fill its tables and reduce its vote correctly."""
+    rng = np.random.default_rng(maxn)
+    fams = [synth_family(int(rng.integers(max(1, maxn // 2), maxn + 1)) if i == 0 else int(rng.integers(1, maxn + 1)), 120, 9,
+                         K=int(rng.integers(20, 120)), seed=4000 + maxn + i, both_sides=True, minus_frac=0.3, n_run_frac=0.3)
+            for i in range(10)]
+    p = po.Params.named("18p43g", bandwidth=9, L=120, when_to_stop=30)
+    cs = [fs.cores.copy() for fs in fams]; ms = [new_master(p.L) for _ in fams]
+    ep = to_extend_params(p)
+    ir = extend_batch(1, [(c, fs.sequence, m) for c, fs, m in zip(cs, fams, ms)], ep)
+    il = extend_batch(0, [(c, fs.sequence, m) for c, fs, m in zip(cs, fams, ms)], ep)
+    for i, fs in enumerate(fams):
+        c = fs.cores.copy(); m = new_master(p.L)
+        r1 = po.oracle_extend(1, c, fs.sequence, m, p)
+        r0 = po.oracle_extend(0, c, fs.sequence, m, p)
+        assert (ir[i].ret, il[i].ret, ir[i].rows_executed, il[i].rows_executed) == (r1.ret, r0.ret, r1.rows_executed, r0.rows_executed), (maxn, i)
+        assert np.array_equal(ms[i], m) and np.array_equal(cs[i].score, c.score), (maxn, i)
+        assert np.array_equal(cs[i].left_len, c.left_len) and np.array_equal(cs[i].right_len, c.right_len), (maxn, i)
+        assert ir[i].persistent == 2
