@@ -116,14 +116,33 @@ int ramx_extend_flat(int direction, ramx_flat_cores *c, const int8_t *sequence, 
   int *map = (int *)malloc(sizeof(int) * (N > 0 ? N : 1));
   ramx_flank *fl = (ramx_flank *)malloc(sizeof(ramx_flank) * (N > 0 ? N : 1));
   const int nx = ramx_resolve_flanks(direction, c, W, L, fl, map);
-  rc = ramx_dev_begin_direction(d, fl, nx, p);
-  info->prep_ms = wall_ms() - t0;
-  if (rc == RAMX_OK) rc = ramx_dev_run_direction(d, info);
-  if (rc != RAMX_OK) { free(map); free(fl); return rc; }
   int8_t *cons = (int8_t *)malloc((size_t)L + 16);
-  int32_t *th = (int32_t *)malloc(sizeof(int32_t) * (nx > 0 ? nx : 1));
-  int32_t *tp = (int32_t *)malloc(sizeof(int32_t) * (nx > 0 ? nx : 1));
-  rc = ramx_dev_download(d, cons, L + 16, th, tp);
+  int32_t *th, *tp;
+  if (nx > 0 && nx <= 512 && L > 0 && W >= 1 && getenv("RAMX_NO_FAMILY_ROUTE") == NULL)
+  {
+    /* a family that fits one workgroup needs no device-wide barrier: run it as a batch of one (block-local vote) */
+    const int npad = (nx + 63) & ~63;
+    ramx_flank *pf = (ramx_flank *)malloc(sizeof(ramx_flank) * (size_t)npad);
+    memcpy(pf, fl, sizeof(ramx_flank) * (size_t)nx);
+    for (int i = nx; i < npad; i++) { memset(&pf[i], 0, sizeof(ramx_flank)); pf[i].t_lo = 1; pf[i].t_hi = 0; pf[i].step = 1; }
+    th = (int32_t *)malloc(sizeof(int32_t) * (size_t)npad);
+    tp = (int32_t *)malloc(sizeof(int32_t) * (size_t)npad);
+    const int32_t first = 0, count = nx;
+    info->prep_ms = wall_ms() - t0;
+    rc = ramx_dev_run_families(d, pf, npad, &first, &count, 1, p, info, cons, th, tp);
+    free(pf);
+    if (rc != RAMX_OK) { free(cons); free(th); free(tp); free(map); free(fl); return rc; }
+  }
+  else
+  {
+    rc = ramx_dev_begin_direction(d, fl, nx, p);
+    info->prep_ms = wall_ms() - t0;
+    if (rc == RAMX_OK) rc = ramx_dev_run_direction(d, info);
+    if (rc != RAMX_OK) { free(cons); free(map); free(fl); return rc; }
+    th = (int32_t *)malloc(sizeof(int32_t) * (nx > 0 ? nx : 1));
+    tp = (int32_t *)malloc(sizeof(int32_t) * (nx > 0 ? nx : 1));
+    rc = ramx_dev_download(d, cons, L + 16, th, tp);
+  }
   if (rc == RAMX_OK)
   {
     /* ram_extend.c:1092-1095 */

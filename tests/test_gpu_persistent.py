@@ -14,6 +14,18 @@ from helpers import assert_same_result, gpu_extend, oracle_extend, run_both_dire
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["one-workgroup route", "device-wide only"])
+def _small_family_route(request, monkeypatch):
+    """Seam 1 runs a family of up to 512 extendable cores as a batch of one (block-local vote); every test of this
+    file runs a second time with that route switched off, so the device-wide persistent kernel keeps its coverage at
+    small sizes."""
+    if request.param == "device-wide only":
+        monkeypatch.setenv("RAMX_NO_FAMILY_ROUTE", "1")
+    else:
+        monkeypatch.delenv("RAMX_NO_FAMILY_ROUTE", raising=False)
+    yield
+
+
 def _run_device(fs, p, direction, monkeypatch, persistent):
     from repeatafterme_amd.device import Device, resolve_flanks
     if persistent:
