@@ -699,6 +699,9 @@ struct PArgs
 #ifndef PRK_FAST_GROUP
 #define PRK_FAST_GROUP 8
 #endif
+#ifndef PRK_FETCH_AHEAD
+#define PRK_FETCH_AHEAD 2
+#endif
 __device__ __forceinline__ int vmax3(int x, int y, int z)   // forced v_max3_i32 (keeps the compiler from re-associating)
 {
   int d;
@@ -797,11 +800,33 @@ __device__ __forceinline__ void prk_band_fast(const int go, const int ge, const 
 #pragma unroll
   for (int g = 0; g < NG; g++) kg[g] = -2147483647 - 1;
   // compile-time cell index: the band is generated step by step (no reliance on the loop unroller, whose size limit
-  // would otherwise leave the row in scratch memory).  Table rows are fetched one step ahead of their use.
-  unsigned A = __builtin_amdgcn_alignbit(w[1], w[0], ph4);
-  unsigned Alo = A & 0x0f0f0f0fu;                   // low nibbles only: (byte << 4) is then the row offset of the class
-  int2 rowN = *reinterpret_cast<const int2 *>(tb + nib_lo_x16<0>(Alo));      // {candidate bytes, M[besta][base]}
-  int dN = (B > 1) ? (int)myD[1] : 0;               // e - m of the previous row's cell j+1, fetched one step ahead too
+  // would otherwise leave the row in scratch memory).  Table rows and the previous row's e are fetched PD steps ahead
+  // of their use (a lone wave per SIMD -- one family per workgroup -- has nobody to hide the LDS latency behind).
+  constexpr int PD = PRK_FETCH_AHEAD;
+  unsigned A = 0, Alo = 0;
+  int2 rowQ[PD];                                    // {candidate bytes, M[besta][base]} of steps j .. j+PD-1
+  int dQ[PD];                                       // e - m of the previous row's cells j+1 .. j+PD
+  auto fetch_row = [&](auto jc) __attribute__((always_inline))
+  {
+    constexpr int jn = decltype(jc)::value;         // the step whose base is looked up
+    if constexpr ((jn & 7) == 0 || jn == 0)
+    {
+      A = __builtin_amdgcn_alignbit(w[(jn >> 3) + 1], w[jn >> 3], ph4);
+      Alo = A & 0x0f0f0f0fu;                        // low nibbles only: (byte << 4) is then the row offset of the class
+    }
+    constexpr int byte = (jn & 7) / 2;
+    unsigned off;
+    if constexpr ((jn & 1) == 0) off = nib_lo_x16<byte>(Alo);
+    else off = nib_hi_x16<byte>(A, mask_f0);
+    return *reinterpret_cast<const int2 *>(tb + off);
+  };
+  static_for([&](auto kc) __attribute__((always_inline))
+  {
+    constexpr int k = decltype(kc)::value;
+    if constexpr (k <= B) rowQ[k] = fetch_row(std::integral_constant<int, (k <= B ? k : 0)>{});
+    else rowQ[k] = make_int2(0, 0);
+    dQ[k] = (k + 1 < B) ? (int)myD[((k + 1) >> 1) * (2 * BLOCK) + ((k + 1) & 1)] : 0;
+  }, std::make_integer_sequence<int, PD>{});
   auto step = [&](auto jc) __attribute__((always_inline))
   {
     constexpr int j = decltype(jc)::value;
@@ -812,24 +837,12 @@ __device__ __forceinline__ void prk_band_fast(const int go, const int ge, const 
       asm volatile("" ::"v"(bA[0]), "v"(bA[1]), "v"(bA[2]), "v"(bA[3]), "v"(maxE), "v"(kg[(j > 0 ? j - 1 : 0) >> 4]));
       __builtin_amdgcn_sched_barrier(0);
     }
-    const int sv = rowN.x, sF = rowN.y;
-    const int dCur = dN;
-    if constexpr (j + 2 < B) dN = (int)myD[((j + 2) >> 1) * (2 * BLOCK) + ((j + 2) & 1)];
-    if constexpr (j + 1 <= B)
-    {
-      constexpr int jn = j + 1;
-      if constexpr ((jn & 7) == 0)
-      {
-        A = __builtin_amdgcn_alignbit(w[(jn >> 3) + 1], w[jn >> 3], ph4);
-        Alo = A & 0x0f0f0f0fu;
-      }
-      constexpr bool lo = (jn & 1) == 0;
-      constexpr int byte = (jn & 7) / 2;
-      unsigned off;
-      if constexpr (lo) off = nib_lo_x16<byte>(Alo);
-      else off = nib_hi_x16<byte>(A, mask_f0);
-      rowN = *reinterpret_cast<const int2 *>(tb + off);
-    }
+    const int sv = rowQ[0].x, sF = rowQ[0].y;
+    const int dCur = dQ[0];
+#pragma unroll
+    for (int k = 0; k + 1 < PD; k++) { rowQ[k] = rowQ[k + 1]; dQ[k] = dQ[k + 1]; }
+    if constexpr (j + PD <= B) rowQ[PD - 1] = fetch_row(std::integral_constant<int, (j + PD <= B ? j + PD : 0)>{});
+    if constexpr (j + PD + 1 < B) dQ[PD - 1] = (int)myD[((j + PD + 1) >> 1) * (2 * BLOCK) + ((j + PD + 1) & 1)];
     // candidates' cell j-1 of row r+1: substitution from m_{j-1} of row r (the base of that cell is this step's)
     if constexpr (j >= 1)
     {
