@@ -1253,7 +1253,7 @@ __global__ __launch_bounds__(BLOCK, 2) void ramx_persistent_kernel(const PArgs a
 // registers / LDS exactly as in the persistent kernel; the boundary row and the candidates of row 0 are produced
 // in-kernel (column "-1").
 
-struct FamDesc { int tile0, ntiles, nx, pad; };     // first 64-flank tile, tiles, flanks of the family
+struct FamDesc { int tile0, ntiles, nx, id; };      // first 64-flank tile, tiles, flanks of the family; its index in the caller's arrays
 
 struct FArgs
 {
@@ -1286,9 +1286,10 @@ __global__ __launch_bounds__(BLOCK, 2) void ramx_family_kernel(const FArgs a)
   short *sD = sm.d;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const FamDesc fd = a.fam[blockIdx.x];
-  const bool live = wave < fd.ntiles;
-  const int n = (fd.tile0 + (live ? wave : 0)) * 64 + lane;
-  const bool active = live && (wave * 64 + lane) < fd.nx;
+  const int vwave = wave;
+  const bool live = vwave < fd.ntiles;
+  const int n = (fd.tile0 + (live ? vwave : 0)) * 64 + lane;
+  const bool active = live && (vwave * 64 + lane) < fd.nx;
 
   for (int i = threadIdx.x; i < 4 * TAB_ROWS * TAB_STRIDE; i += BLOCK)
   {
@@ -1308,13 +1309,21 @@ __global__ __launch_bounds__(BLOCK, 2) void ramx_family_kernel(const FArgs a)
   long long max_ext = 0;
   int max_row = -1, rows_done = 0, ovf = 0, stopped = 0;
 
+  // base words of the lane's window: the window moves by one nibble per column, so the words are carried across
+  // columns and ONE new word is loaded every eighth column (its first use is at the far end of the band)
+  unsigned w[NW];
+  {
+    const unsigned *bp = a.bases + n;               // column -1 starts at word (r + 8) >> 3 = 0
+#pragma unroll
+    for (int k = 0; k < NW; k++) w[k] = bp[(size_t)k * a.Np];
+  }
   for (int r = -1; r < a.L; r++)
   {
-    unsigned w[NW];
+    if (r >= 0 && ((r + 8) & 7) == 0)
     {
-      const unsigned *bp = a.bases + (size_t)((r + 8) >> 3) * a.Np + n;
 #pragma unroll
-      for (int k = 0; k < NW; k++) w[k] = bp[(size_t)k * a.Np];
+      for (int k = 0; k + 1 < NW; k++) w[k] = w[k + 1];
+      w[NW - 1] = a.bases[(size_t)(((r + 8) >> 3) + NW - 1) * a.Np + n];
     }
     int besta = 0;
     bool new_max = false;
@@ -1325,9 +1334,12 @@ __global__ __launch_bounds__(BLOCK, 2) void ramx_family_kernel(const FArgs a)
 #pragma unroll
       for (int k = 0; k < 4; k++)
       {
-        long long vk = 0;
+        long long vv = 0;
 #pragma unroll
-        for (int wv = 0; wv < WPB; wv++) vk += s_red[r & 1][wv][k];
+        for (int wv = 0; wv < WPB; wv++) vv += s_red[r & 1][wv][k];
+        // wave-uniform: keep the vote and the stop rule on the scalar unit (see the persistent kernel)
+        const long long vk = ((long long)__builtin_amdgcn_readfirstlane((int)(vv >> 32)) << 32) |
+                             (long long)(unsigned)__builtin_amdgcn_readfirstlane((int)vv);
         if (vk > 2147483647LL || vk < -2147483648LL) ovf = 1;
         if (vk > curr) { curr = vk; besta = k; }
       }
@@ -1339,7 +1351,7 @@ __global__ __launch_bounds__(BLOCK, 2) void ramx_family_kernel(const FArgs a)
       d2 = d2 < 0 ? -d2 : d2;
       stopped = d2 >= a.when_to_stop;
       rows_done = r + 1;
-      if (threadIdx.x == 0) a.cons_out[(size_t)blockIdx.x * a.L + r] = (signed char)besta;
+      if (threadIdx.x == 0) a.cons_out[(size_t)fd.id * a.L + r] = (signed char)besta;
     }
     const int *s_tab = s_tab4[besta];
     if (r >= 0 && a.pack_ok)
@@ -1395,7 +1407,7 @@ __global__ __launch_bounds__(BLOCK, 2) void ramx_family_kernel(const FArgs a)
   {
     RamxCtl o;
     o.max_ext = max_ext; o.max_row = max_row; o.stopped = stopped; o.rows_done = rows_done; o.overflow = ovf; o.besta = 0; o.pad = 0;
-    a.ctl_out[blockIdx.x] = o;
+    a.ctl_out[fd.id] = o;
   }
 }
 
@@ -1467,7 +1479,7 @@ __global__ __launch_bounds__(BLOCK) void ramx_family_stream_kernel(const FSArgs 
       d2 = d2 < 0 ? -d2 : d2;
       stopped = d2 >= a.when_to_stop;
       rows_done = r + 1;
-      if (threadIdx.x == 0) fa.cons_out[(size_t)blockIdx.x * fa.L + r] = (signed char)besta;
+      if (threadIdx.x == 0) fa.cons_out[(size_t)fd.id * fa.L + r] = (signed char)besta;
     }
     // the winner's score table; everybody has left the previous column's band (barrier at its end)
     for (int i = threadIdx.x; i < TAB_ROWS * TAB_STRIDE; i += BLOCK)      // BLOCK may be 64: fewer threads than entries
@@ -1524,7 +1536,7 @@ __global__ __launch_bounds__(BLOCK) void ramx_family_stream_kernel(const FSArgs 
   {
     RamxCtl o;
     o.max_ext = max_ext; o.max_row = max_row; o.stopped = stopped; o.rows_done = rows_done; o.overflow = ovf; o.besta = 0; o.pad = 0;
-    fa.ctl_out[blockIdx.x] = o;
+    fa.ctl_out[fd.id] = o;
   }
 }
 
@@ -1556,6 +1568,7 @@ struct ramx_dev
   // host-memory variant of the boxes (POSIX shared memory registered with HIP): xbox/peer point into it
   void *hostbox_map; size_t hostbox_bytes; PeerBox *hostbox_host; int hostbox_registered;
   PeerBox *devbox;     // this rank's fine-grained device-memory box (exported over hipIpc)
+  hipStream_t cls_stream[4]; hipEvent_t cls_ready, cls_done[4]; int cls_init;   // batch mode: one stream per workgroup shape
   int force_chain;   // RAMX_FORCE_CHAIN=1: always run the full candidate recurrence (test hook)
 };
 
@@ -1613,6 +1626,11 @@ extern "C" void ramx_dev_destroy(ramx_dev *d)
   {
     if (d->hostbox_registered) (void)hipHostUnregister(d->hostbox_map);
     munmap(d->hostbox_map, d->hostbox_bytes);
+  }
+  if (d->cls_init)
+  {
+    for (int c = 0; c < 4; c++) { (void)hipStreamDestroy(d->cls_stream[c]); (void)hipEventDestroy(d->cls_done[c]); }
+    (void)hipEventDestroy(d->cls_ready);
   }
   if (d->devbox) (void)hipFree(d->devbox);
   if (d->d_peer) (void)hipFree(d->d_peer);
@@ -2038,9 +2056,10 @@ static int prk_run(ramx_dev *d, const KArgs &a, int L, bool *used)
 
 // ---- batch mode -------------------------------------------------------------------------------
 template <int W, int BLOCK>
-static int fam_launch(ramx_dev *d, const FArgs &fa, int F)
+static int fam_launch(ramx_dev *d, const FArgs &fa, int F, hipStream_t st)
 {
-  hipLaunchKernelGGL((ramx_family_kernel<W, BLOCK>), dim3(F), dim3(BLOCK), 0, d->stream, fa);
+  (void)d;
+  hipLaunchKernelGGL((ramx_family_kernel<W, BLOCK>), dim3(F), dim3(BLOCK), 0, st, fa);
   HIPCHK(hipGetLastError());
   return RAMX_OK;
 }
@@ -2075,11 +2094,20 @@ extern "C" int ramx_dev_run_families(ramx_dev *d, const ramx_flank *flanks, int3
   HIPCHK(hipMalloc((void **)&d->d_bounds, (size_t)Np * sizeof(int2)));
   HIPCHK(hipMalloc((void **)&d->d_trim, (size_t)Np * sizeof(int2)));
   if ((rc = ensure(&d->d_cons, &d->cap_cons, (size_t)n_families * (L > 0 ? L : 1) + 16))) return rc;
+  // descriptors grouped by workgroup shape (64, 128, 256, 512 threads = 1, 2, 4, 8 tiles): one launch per non-empty
+  // class, so a 100-flank family occupies two waves, not four
   FamDesc *hfd = (FamDesc *)malloc(sizeof(FamDesc) * n_families);
-  for (int f = 0; f < n_families; f++)
+  int cls_first[5] = { 0, 0, 0, 0, 0 }, cls_count[4] = { 0, 0, 0, 0 };
+  auto cls_of = [](int nx) { return nx <= 64 ? 0 : nx <= 128 ? 1 : nx <= 256 ? 2 : 3; };
+  for (int f = 0; f < n_families; f++) cls_count[cls_of(fam_count[f])]++;
+  for (int c = 0; c < 4; c++) cls_first[c + 1] = cls_first[c] + cls_count[c];
   {
-    hfd[f].tile0 = fam_first[f] / 64; hfd[f].ntiles = (fam_count[f] + 63) / 64; hfd[f].nx = fam_count[f]; hfd[f].pad = 0;
-    if (hfd[f].ntiles == 0) hfd[f].ntiles = 0;
+    int fill[4] = { cls_first[0], cls_first[1], cls_first[2], cls_first[3] };
+    for (int f = 0; f < n_families; f++)
+    {
+      FamDesc &x = hfd[fill[cls_of(fam_count[f])]++];
+      x.tile0 = fam_first[f] / 64; x.ntiles = (fam_count[f] + 63) / 64; x.nx = fam_count[f]; x.id = f;
+    }
   }
   FamDesc *dfd = NULL; RamxCtl *dctl = NULL;
   HIPCHK(hipMalloc((void **)&dfd, sizeof(FamDesc) * n_families));
@@ -2102,6 +2130,15 @@ extern "C" int ramx_dev_run_families(ramx_dev *d, const ramx_flank *flanks, int3
   }
   fa.pack_ok = getenv("RAMX_NO_FASTPACK") ? 0 : fast_pack_ok(fa.tab, fa.go, fa.ge, L, W);
   HIPCHK(hipEventRecord(d->ev_begin, d->stream));
+  // the shapes run side by side: one stream per class, forked from / joined into the library's stream
+  if (!d->cls_init)
+  {
+    for (int c = 0; c < 4; c++) { HIPCHK(hipStreamCreateWithFlags(&d->cls_stream[c], hipStreamNonBlocking)); HIPCHK(hipEventCreateWithFlags(&d->cls_done[c], hipEventDisableTiming)); }
+    HIPCHK(hipEventCreateWithFlags(&d->cls_ready, hipEventDisableTiming));
+    d->cls_init = 1;
+  }
+  HIPCHK(hipEventRecord(d->cls_ready, d->stream));
+  for (int c = 0; c < 4; c++) if (cls_count[c] > 0) HIPCHK(hipStreamWaitEvent(d->cls_stream[c], d->cls_ready, 0));
   if (!resident)
   {
     // rows of every family in the (in-place) row buffer: 16 B x (W + 1) slots per flank
@@ -2123,20 +2160,34 @@ extern "C" int ramx_dev_run_families(ramx_dev *d, const ramx_flank *flanks, int3
     memcpy(fs.k.tab, fa.tab, sizeof(fs.k.tab));
     fs.fam = dfd; fs.ctl_out = dctl; fs.cons_out = d->d_cons; fs.L = L;
     const bool chain = p->gapopen > 0 || p->gapextn > 0 || d->force_chain;
-    const int blk = maxn <= 64 ? 64 : maxn <= 128 ? 128 : maxn <= 256 ? 256 : 512;
-#define RAMX_FS_LAUNCH(CH, BL) hipLaunchKernelGGL((ramx_family_stream_kernel<CH, BL>), dim3(n_families), dim3(BL), 0, d->stream, fs)
-    if (chain) { if (blk == 64) RAMX_FS_LAUNCH(true, 64); else if (blk == 128) RAMX_FS_LAUNCH(true, 128); else if (blk == 256) RAMX_FS_LAUNCH(true, 256); else RAMX_FS_LAUNCH(true, 512); }
-    else { if (blk == 64) RAMX_FS_LAUNCH(false, 64); else if (blk == 128) RAMX_FS_LAUNCH(false, 128); else if (blk == 256) RAMX_FS_LAUNCH(false, 256); else RAMX_FS_LAUNCH(false, 512); }
+#define RAMX_FS_LAUNCH(CH, BL, C) do { if (cls_count[C] > 0) { fs.fam = dfd + cls_first[C]; \
+      hipLaunchKernelGGL((ramx_family_stream_kernel<CH, BL>), dim3(cls_count[C]), dim3(BL), 0, d->cls_stream[C], fs); } } while (0)
+    if (chain) { RAMX_FS_LAUNCH(true, 64, 0); RAMX_FS_LAUNCH(true, 128, 1); RAMX_FS_LAUNCH(true, 256, 2); RAMX_FS_LAUNCH(true, 512, 3); }
+    else { RAMX_FS_LAUNCH(false, 64, 0); RAMX_FS_LAUNCH(false, 128, 1); RAMX_FS_LAUNCH(false, 256, 2); RAMX_FS_LAUNCH(false, 512, 3); }
 #undef RAMX_FS_LAUNCH
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) { free(hfd); ramx_set_error("family stream kernel launch: %s", hipGetErrorString(le)); return RAMX_ERR_HIP; }
     rc = RAMX_OK;
   }
-  else if (maxn <= 256)
-    rc = (W == 14) ? fam_launch<14, 256>(d, fa, n_families) : (W == 20) ? fam_launch<20, 256>(d, fa, n_families) : fam_launch<40, 256>(d, fa, n_families);
   else
-    rc = (W == 14) ? fam_launch<14, 512>(d, fa, n_families) : (W == 20) ? fam_launch<20, 512>(d, fa, n_families) : fam_launch<40, 512>(d, fa, n_families);
+  {
+    // the register-resident kernel gains nothing from smaller workgroups (measured: 11.5 vs 10.3 ms; rotating the live
+    // waves over the SIMDs by arrival order on the CU did not help either): 256 threads up to 256 flanks, in class order
+    cls_count[2] += cls_count[0] + cls_count[1]; cls_first[2] = 0; cls_count[0] = cls_count[1] = 0;
+    rc = RAMX_OK;
+    for (int c = 0; c < 4 && rc == RAMX_OK; c++)
+    {
+      if (cls_count[c] == 0) continue;
+      fa.fam = dfd + cls_first[c];
+      const int n = cls_count[c];
+      hipStream_t st = d->cls_stream[c];
+      if (c <= 2) rc = (W == 14) ? fam_launch<14, 256>(d, fa, n, st) : (W == 20) ? fam_launch<20, 256>(d, fa, n, st) : fam_launch<40, 256>(d, fa, n, st);
+      else             rc = (W == 14) ? fam_launch<14, 512>(d, fa, n, st) : (W == 20) ? fam_launch<20, 512>(d, fa, n, st) : fam_launch<40, 512>(d, fa, n, st);
+    }
+  }
   if (rc != RAMX_OK) { free(hfd); return rc; }
+  for (int c = 0; c < 4; c++)
+    if (cls_count[c] > 0) { HIPCHK(hipEventRecord(d->cls_done[c], d->cls_stream[c])); HIPCHK(hipStreamWaitEvent(d->stream, d->cls_done[c], 0)); }
   HIPCHK(hipEventRecord(d->ev_end, d->stream));
   HIPCHK(hipStreamSynchronize(d->stream));
   float ms = 0;
