@@ -192,7 +192,7 @@ int ramx_dev_run_direction(ramx_dev *d, ramx_run_info *info);
 int ramx_dev_download(ramx_dev *d, int8_t *cons, int32_t cons_cap, int32_t *trim_high, int32_t *trim_pos);
 
 /* debug / test hook: current DP row state of one flank as [2W+1][2] int32 + high,pos.  The device stores each
- * cell transformed: (m, e) = (max(sub,gap), max(sub+gapopen,gap)+gapextn) -- see csrc/ramx_device.hip. */
+ * cell transformed: (m, e) = (max(sub,gap), max(sub+gapopen,gap)+gapextn) -- see csrc/ramx_kernels_common.h. */
 int ramx_dev_peek_state(ramx_dev *d, int32_t flank, int32_t *cells, int32_t *high, int32_t *pos);
 
 /* Batch mode (no counterpart in the reference, whose wrapper util/extend-stk.pl:242-371 starts one

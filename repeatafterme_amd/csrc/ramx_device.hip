@@ -32,8 +32,6 @@
 // loop inside the lane, so the values are the reference's bit for bit; parallelism comes from the
 // flanks (N >= 64 k fills the chip).  No MFMA: integer max-plus recurrences, HBM-bound.
 
-#include <hip/hip_runtime.h>
-#include <utility>
 #include <rccl/rccl.h>
 #include <errno.h>
 #include <fcntl.h>
@@ -45,41 +43,10 @@
 #include <string.h>
 #include <time.h>
 
-#include "ramx_internal.h"
 
-#define NEG RAMX_NEG_IMPOSSIBLE
-#define SENT RAMX_OOB_SENTINEL
-#define NSHARD 32
-#define PF 8            // state slots kept in flight per lane
-#define MAX_SAMPLES 64
-
-struct RamxCtl
-{
-  long long max_ext;   // max_extension_score
-  int max_row;         // max_extension_score_row_idx
-  int stopped;
-  int rows_done;       // row_idx iterations executed so far
-  int overflow;        // a column sum left the int32 range
-  int besta;
-  int pad;
-};
-
-struct KArgs
-{
-  const int4 *S_in;
-  int4 *S_out;
-  const unsigned *bases;
-  const int2 *bounds;
-  int2 *trim;
-  const long long *sums_in;
-  long long *sums_out;
-  long long *sums_zero;
-  const RamxCtl *ctl_in;
-  RamxCtl *ctl_out;
-  signed char *cons_out;
-  int Np, Nx, W, r, go, ge, cap, minimp, when_to_stop, nshards_in;
-  int tab[RAMX_NCLASS][4];   // tab[class][candidate] = matrix[candidate][class]
-};
+#include "ramx_kernels_common.h"
+#include "ramx_kernels_stream.h"
+#include "ramx_kernels_resident.h"
 
 // ------------------------------------------------------------------------------------------
 // error plumbing
@@ -109,1435 +76,6 @@ static double now_ms(void)
   struct timespec ts;
   clock_gettime(CLOCK_MONOTONIC, &ts);
   return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
-}
-
-// ------------------------------------------------------------------------------------------
-// pack kernel: 1-byte library -> transposed, pre-oriented 4-bit windows
-// ------------------------------------------------------------------------------------------
-__global__ void ramx_pack_kernel(const signed char *__restrict__ lib, unsigned long long lib_len,
-                                 const ramx_flank *__restrict__ fl, int Nx, int Np, int W,
-                                 unsigned *__restrict__ bases, int2 *__restrict__ bounds)
-{
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  const int k = blockIdx.y;
-  if (n >= Np) return;
-  unsigned word = 0x88888888u;   // class 8 = N everywhere
-  if (n < Nx)
-  {
-    const ramx_flank f = fl[n];
-    word = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++)
-    {
-      const int t = 8 * k + i - W - 8;   // one leading pad word: nibble index t'' = t + W + 8
-      unsigned c = 8;
-      if (t >= f.t_lo && t <= f.t_hi)
-      {
-        const long long p = f.start + (long long)f.step * t;
-        if (p >= 0 && (unsigned long long)p < lib_len)
-        {
-          const int b = lib[p];
-          if (b >= 0 && b <= 7)   // A C G T a c g t; complement keeps the case (sequence.c:1141-1160)
-            c = f.compl_ ? (unsigned)((b & 4) | (3 - (b & 3))) : (unsigned)b;
-        }
-      }
-      word |= c << (4 * i);
-    }
-    if (k == 0) bounds[n] = make_int2(f.t_lo + W, f.t_hi + W);
-  }
-  else if (k == 0)
-    bounds[n] = make_int2(1, 0);   // empty interval: every cell out of bounds
-  bases[(size_t)k * Np + n] = word;
-}
-
-// ------------------------------------------------------------------------------------------
-// column kernel
-// ------------------------------------------------------------------------------------------
-//
-// State kept per band cell (two int32, as in the reference's score[..][..][2]) is stored TRANSFORMED:
-//     m  = max(sub, gap)                  -- all the next row's substitution term needs   (bnw_extend.c:950-956)
-//     e  = max(sub + go, gap) + ge        -- all the next row's deletion term needs       (:892-905), and, read
-//                                            from the current row's previous cell, the insertion term (:972-985)
-// (sub, gap) -> (m, e) loses nothing the recurrence ever reads, and saves three VALU ops per cell per row.
-//
-// Candidate rows (row r+1 for A,C,G,T; only their best cell is needed, ram_extend.c:1005-1062).  With
-// go <= 0 and ge <= 0 (every built-in scoring system) the insertion chain can never hold the row maximum:
-//   emit_k = max(sub_k + go, gap_k) <= cell_k,  ins_{k+1} = emit_k + ge <= cell_k, and for a masked cell
-//   emit = max(v + go, v) = v = cell; by induction  max_k cell_k = max_k [ inb_k ? max(sub_k, del_k) : v_k ].
-// So CHAIN = false evaluates the four candidates with NO serial chain: sub_k = m_k + M[a][base] and the shared
-// del_k = e_{k+1}.  CHAIN = true keeps the full recurrence for user-supplied positive penalties.
-
-__device__ __forceinline__ long long wave_sum_ll(long long v)
-{
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-  return v;
-}
-
-// Sum over the wave of a value in [0, 2^31) per lane, without touching LDS: two 32-bit DPP reductions (low and high
-// 16 bits; 64 lanes x 2^16 fits), total read from lane 63.  Six VALU steps each instead of six ds_bpermute pairs.
-__device__ __forceinline__ unsigned wave_sum_u32_dpp(unsigned v)
-{
-  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false);    // quad_perm:[1,0,3,2]
-  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false);    // quad_perm:[2,3,0,1]
-  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xf, 0xf, false);   // row_ror:4
-  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, false);   // row_ror:8  -> row totals everywhere
-  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
-  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
-  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
-}
-__device__ __forceinline__ long long wave_sum_nonneg31(int v)
-{
-  const unsigned lo = wave_sum_u32_dpp((unsigned)v & 0xffffu), hi = wave_sum_u32_dpp((unsigned)v >> 16);
-  return ((long long)hi << 16) + (long long)lo;
-}
-
-// The DP rows are written once per column and read once by the next launch.  Plain (cacheable) accesses are the
-// measured choice: the 131 MB ping-pong working set of the N = 100,000 workload stays largely resident in the
-// 256 MB Infinity Cache between launches; non-temporal accesses (-DRAMX_NT_LDST) were 25 % slower
-// (32.5 vs 26.1 us per column, profiles/r01_notes.md).
-__device__ __forceinline__ int4 ld_stream(const int4 *p)
-{
-#ifndef RAMX_NT_LDST
-  return *p;
-#else
-  typedef int v4i __attribute__((ext_vector_type(4)));
-  const v4i v = __builtin_nontemporal_load(reinterpret_cast<const v4i *>(p));
-  return make_int4(v.x, v.y, v.z, v.w);
-#endif
-}
-__device__ __forceinline__ void st_stream(int4 *p, int4 v)
-{
-#ifndef RAMX_NT_LDST
-  *p = v;
-#else
-  typedef int v4i __attribute__((ext_vector_type(4)));
-  v4i x; x.x = v.x; x.y = v.y; x.z = v.z; x.w = v.w;
-  __builtin_nontemporal_store(x, reinterpret_cast<v4i *>(p));
-#endif
-}
-
-__device__ __forceinline__ int imax(int x, int y) { return x > y ? x : y; }
-__device__ __forceinline__ int imax3(int x, int y, int z) { return imax(imax(x, y), z); }
-__device__ __forceinline__ int imed3(int x, int lo, int hi)   // median of three = clamp(x, lo, hi) for lo <= hi
-{
-  int d;
-  asm("v_med3_i32 %0, %1, %2, %3" : "=v"(d) : "v"(x), "v"(lo), "v"(hi));
-  return d;
-}
-
-// Per-lane running values of the skewed pair {row r, candidate rows r+1}.
-struct LaneDP
-{
-  int eC;        // e of row r cell j-1: the insertion term of cell j, and the deletion term of candidate cell j-2
-  int mPrev;     // m of row r cell j-1: the substitution predecessor of candidate cell j-1
-  int bestF, jbest;
-  int eA[4];     // CHAIN only: e of the candidates' previous cell
-  int bestA[4];
-};
-
-// Uniform (scalar) per-step quantities.
-struct StepU
-{
-  int j;         // band cell of row r handled by this step (candidates handle cell j-1 of row r+1)
-  int vF;        // OOB fill of row r   cell j    (bnw_extend.c:990-1002)
-  int vC;        // OOB fill of row r+1 cell j-1, or the "no such cell" value at j == 0
-  bool first;    // j == 0: there is no candidate cell -1
-  int hi;        // CHAIN fast path: upper clamp of the candidates' gap state (INT_MAX; NEG - ge at step 0)
-};
-
-// LDS score table: row b (base class 0..8, row 9 = zeros for masked cells) holds
-// {M[A][b], M[C][b], M[G][b], M[T][b], M[besta][b], 0, 0, 0}; 32 B rows.
-#define TAB_ROWS 10
-#define TAB_STRIDE 8
-
-// Table values of one step, fetched from LDS ahead of use (the lookups depend only on the base stream and
-// the bounds, never on the DP chain, so they are issued one slot early to hide the LDS latency).
-struct StepT
-{
-  int sF;        // M[besta][base]: substitution score of row r cell j
-  int4 s;        // M[A..T][base] (zeros when the candidates' cell is masked)
-  bool inb;      // t' = j + r inside the flank
-  bool inbC;     // inb && j > 0
-};
-
-template <bool OOB>
-__device__ __forceinline__ StepT fetch_step(const int *s_tab, unsigned bc, bool inb, bool first)
-{
-  StepT t;
-  t.inb = OOB ? inb : true;
-  t.inbC = OOB ? (inb && !first) : true;
-#ifdef RAMX_DBG_NOLDS   // timing ablation only
-  t.sF = (int)bc - 3;
-  t.s = make_int4((int)bc, (int)bc - 1, (int)bc - 2, 3 - (int)bc);
-#else
-  t.sF = s_tab[bc * TAB_STRIDE + 4];
-  const unsigned bcC = (OOB && !t.inbC) ? 9u : bc;   // row 9 of the table is all zeros
-  t.s = *reinterpret_cast<const int4 *>(s_tab + bcC * TAB_STRIDE);
-#endif
-  return t;
-}
-
-// One band step.  FIN: compute row r cell j from the previous row (Pm = m of cell j, PeNext = e of cell j+1);
-// !FIN (virtual step j == B): only the candidates' last cell.  INIT: row "r" is the boundary row
-// (ram_extend.c:909-946).  OOB = false is the fast path taken by a wave whose 64 flanks all cover the whole
-// band of both rows: no bounds selects at all.
-template <bool INIT, bool FIN, bool OOB, bool CHAIN>
-__device__ __forceinline__ void band_step(const int go, const int ge, const int W, const StepU u, const StepT t,
-                                          const int Pm, const int PeNext, LaneDP &L, int &outM, int &outE)
-{
-  int eCn, m = 0;
-  if (FIN)
-  {
-    int sub, gap;
-    if (INIT)
-    {
-      const int o = u.j - W;
-      sub = (o == 0) ? 0 : (go + (o < 0 ? -o : o) * ge);
-      gap = sub;
-    }
-    else
-    {
-      sub = Pm + t.sF;                             // bnw_extend.c:950-956
-      gap = imax(L.eC, PeNext);                    // ins (:972-985) vs del (:892-905), :1007-1010
-      if (OOB)
-      {
-        sub = t.inb ? sub : u.vF;                  // :990-1002
-        gap = t.inb ? gap : u.vF;
-      }
-    }
-    m = imax(sub, gap);                            // :1015-1018
-    if (!INIT)
-    {
-      const bool better = m > L.bestF;             // :1020-1024 strict >: lowest offset wins ties
-      L.bestF = imax(m, L.bestF);
-      L.jbest = better ? u.j : L.jbest;
-    }
-    eCn = imax(sub + go, gap) + ge;
-    outM = m;
-    outE = eCn;
-  }
-  else
-    eCn = NEG;                                     // cell B does not exist: candidates' del is exactly NEG
-  // candidates: cell j-1 of row r+1 for all four bases, from S(r) just computed (never stored)
-  const int sv[4] = { t.s.x, t.s.y, t.s.z, t.s.w };
-  if (CHAIN)
-  {
-    int mSel, lo, hi;
-    if (OOB)
-    {
-      mSel = t.inbC ? L.mPrev : u.vC;              // masked cell: sub = gap = vC
-      lo = t.inbC ? eCn : u.vC;                    // del of the candidates (shared by the four)
-      hi = t.inbC ? 2147483647 : u.vC;
-    }
-    else
-    {
-      mSel = L.mPrev;                              // at step 0 this is the very negative initial value
-      lo = eCn;
-      hi = u.hi;                                   // INT_MAX, or NEG - ge at step 0: median(NEG, lo, hi) = NEG - ge
-    }
-#pragma unroll
-    for (int c = 0; c < 4; c++)
-    {
-      const int subA = mSel + sv[c];
-      const int gapA = imed3(L.eA[c], lo, hi);     // in bounds: max(ins, del); masked: vC
-      L.bestA[c] = imax3(L.bestA[c], subA, gapA);
-      L.eA[c] = imax(subA + go, gapA) + ge;
-    }
-  }
-  else
-  {
-    int mSel, lo;
-    if (OOB)
-    {
-      mSel = t.inbC ? L.mPrev : u.vC;
-      lo = t.inbC ? eCn : u.vC;
-    }
-    else
-    {
-      mSel = L.mPrev;
-      lo = u.first ? NEG : eCn;                    // there is no candidate cell -1 to take e[0] as its deletion
-    }
-#pragma unroll
-    for (int c = 0; c < 4; c++) L.bestA[c] = imax3(L.bestA[c], mSel + sv[c], lo);
-  }
-  L.mPrev = m;
-  L.eC = eCn;
-}
-
-// The whole band of one flank (one lane) for column r: streams S(r-1) in, S(r) out.
-template <bool INIT, bool OOB, bool CHAIN>
-__device__ __forceinline__ void run_band(const KArgs &a, const int r, const int *s_tab, const int4 *Sin, int4 *Sout,
-                                         const unsigned *bp, const int jlo, const int jhi, LaneDP &D, int &high, int &pos,
-                                         int4 (&buf)[PF], int4 (&far)[PF], unsigned w0, unsigned w1, unsigned w2)
-{
-  const int W = a.W, B = 2 * W + 1, Q = W + 1, go = a.go, ge = a.ge;
-  // OOB fill values (bnw_extend.c:990-1002): uniform per (row, cell)
-  const int edgeF = (r < W) ? go + (r + 1) * ge : SENT;        // row r,   cells j < W
-  const int edgeC = (r + 1 < W) ? go + (r + 2) * ge : SENT;    // row r+1, cells j-1 < W
-  const int vFirst = NEG - ge - (go > 0 ? go : 0);             // CHAIN: leaves eA = NEG after the masked step 0
-  const int ph4 = 4 * ((r + 8) & 7);
-  const size_t wstride = (size_t)a.Np;
-  auto make_u = [&](int j) {
-    StepU u;
-    u.j = j;
-    u.first = (j == 0);
-    u.hi = u.first ? NEG - ge : 2147483647;
-    if (OOB)
-    {
-      u.vF = (j < W) ? edgeF : SENT;
-      u.vC = u.first ? vFirst : ((j - 1 < W) ? edgeC : SENT);
-    }
-    else { u.vF = 0; u.vC = 0; }
-    return u;
-  };
-  // table lookups of the two steps of slot q (bc0/bc1: base classes of steps 2q and 2q+1)
-  auto fetch_slot = [&](int q, unsigned bc0, unsigned bc1, StepT &t0, StepT &t1) {
-    const int j0 = 2 * q, j1 = 2 * q + 1;
-    t0 = fetch_step<OOB>(s_tab, bc0, (j0 >= jlo) && (j0 <= jhi), j0 == 0);
-    t1 = fetch_step<OOB>(s_tab, bc1, (j1 >= jlo) && (j1 <= jhi), false);
-  };
-  // One regular slot q = (m,e) of cells 2q and 2q+1 of row r; candidate cells 2q-1 and 2q of row r+1.
-  auto regular_slot = [&](int q, int4 cur, int4 nxt, const StepT &t0, const StepT &t1) {
-    int m0, e0, m1, e1;
-    band_step<INIT, true, OOB, CHAIN>(go, ge, W, make_u(2 * q), t0, cur.x, cur.w, D, m0, e0);
-    band_step<INIT, true, OOB, CHAIN>(go, ge, W, make_u(2 * q + 1), t1, cur.z, nxt.y, D, m1, e1);
-#if defined(RAMX_DBG_NOMEM) || defined(RAMX_DBG_NOSTORE)
-    if (m0 == 0x7fffffff) Sout[(size_t)q * 64] = make_int4(m0, e0, m1, e1);
-#else
-    st_stream(Sout + (size_t)q * 64, make_int4(m0, e0, m1, e1));
-#endif
-  };
-  auto final_slot = [&](int4 cur, const StepT &t0, const StepT &t1) {
-    int m0, e0, m1, e1;
-    // cell B-1 has no deletion predecessor (bnw_extend.c:892); then the virtual step j = B
-    band_step<INIT, true, OOB, CHAIN>(go, ge, W, make_u(2 * W), t0, cur.x, NEG, D, m0, e0);
-    band_step<INIT, false, OOB, CHAIN>(go, ge, W, make_u(B), t1, 0, 0, D, m1, e1);
-    if (!INIT)
-    {
-      high = cur.z; pos = cur.w;
-      if (D.bestF > high) { high = D.bestF; pos = r + D.jbest - W; }   // ram_extend.c:1140-1150
-    }
-    st_stream(Sout + (size_t)W * 64, make_int4(m0, e0, high, pos));
-  };
-  auto nib = [](unsigned A0, unsigned A1, int k) { return ((k < 8 ? A0 : A1) >> (4 * (k & 7))) & 15u; };
-
-  // ---- full groups: 8 slots = 16 steps of branch-free straight-line code -------------------
-  const int G = W >> 3;
-  int q0 = 0;
-  unsigned A0 = __builtin_amdgcn_alignbit(w1, w0, ph4);
-  unsigned A1 = __builtin_amdgcn_alignbit(w2, w1, ph4);
-  StepT t0, t1;
-  fetch_slot(0, nib(A0, A1, 0), nib(A0, A1, 1), t0, t1);
-  for (int g = 0; g < G; g++, q0 += 8)
-  {
-    const unsigned *bq = bp + (size_t)(2 * g + 3) * wstride;
-    const unsigned w3 = bq[0], w4 = bq[wstride];               // next group's words, consumed at the END of this group
-#pragma unroll
-    for (int i = 0; i < PF; i++)
-    {
-      const int q = q0 + i;
-      int4 cur = make_int4(0, 0, 0, 0), nxt = cur;
-      if (!INIT)
-      {
-        cur = buf[i];
-        nxt = buf[(i + 1) % PF];
-        buf[i] = far[i];
-        const int qn = q + 2 * PF;
-#ifdef RAMX_DBG_NOMEM   // timing ablation only
-        far[i] = make_int4(cur.x + 1, cur.y - 1, cur.z + 2, cur.w - 2);
-#else
-        far[i] = ld_stream(Sin + (size_t)(qn < Q ? qn : Q - 1) * 64);
-#endif
-      }
-      StepT n0, n1;                                            // lookups of the NEXT slot, issued before this one's math
-      if (i + 1 < PF) fetch_slot(q + 1, nib(A0, A1, 2 * i + 2), nib(A0, A1, 2 * i + 3), n0, n1);
-      else
-      {
-        A0 = __builtin_amdgcn_alignbit(w3, w2, ph4);
-        A1 = __builtin_amdgcn_alignbit(w4, w3, ph4);
-        fetch_slot(q + 1, nib(A0, A1, 0), nib(A0, A1, 1), n0, n1);
-      }
-      regular_slot(q, cur, nxt, t0, t1);
-      t0 = n0; t1 = n1;
-    }
-    w0 = w2; w1 = w3; w2 = w4;
-  }
-  // ---- tail group: remaining regular slots (W % 8 of them) and the final slot ---------------
-#pragma unroll
-  for (int i = 0; i < PF; i++)
-  {
-    const int q = q0 + i;
-    if (q <= W)
-    {
-      int4 cur = make_int4(0, 0, 0, 0), nxt = cur;
-      if (!INIT) { cur = buf[i]; nxt = buf[(i + 1) % PF]; }
-      if (q < W)
-      {
-        StepT n0, n1;
-        fetch_slot(q + 1, nib(A0, A1, (2 * i + 2) & 15), nib(A0, A1, (2 * i + 3) & 15), n0, n1);
-        regular_slot(q, cur, nxt, t0, t1);
-        t0 = n0; t1 = n1;
-      }
-      else
-        final_slot(cur, t0, t1);
-    }
-  }
-}
-
-template <bool INIT, bool CHAIN, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void ramx_column_kernel(const KArgs a)
-{
-  constexpr int WPB = BLOCK / 64;
-  __shared__ __attribute__((aligned(16))) int s_tab[TAB_ROWS * TAB_STRIDE];
-  __shared__ long long s_red[WPB][4];
-  const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-
-  // ---- loads that do not depend on the vote are issued first, so that the prologue below (a dependent
-  // round trip to the control block and the vote shards) overlaps with them: two rings of PF slots
-  // (`buf` = slots 0..7, `far` = 8..15; inside the band every load is issued 2*PF slots = 32 band steps ahead
-  // of its use, ~16 KB in flight per wave), the flank bounds and the first three base words.
-  const int W = a.W, B = 2 * W + 1, Q = W + 1, r = a.r;
-  const int tile = blockIdx.x * WPB + wave;
-  const bool live = tile < (a.Np >> 6);
-  const int n = (live ? tile : 0) * 64 + lane;
-  const int4 *Sin = a.S_in + (size_t)(live ? tile : 0) * Q * 64 + lane;
-  int4 *Sout = a.S_out + (size_t)(live ? tile : 0) * Q * 64 + lane;
-  // base stream: step j reads nibble t'' = j + r + 8 (the packed windows carry one leading pad word so that
-  // r = -1 stays non-negative); per group of 16 steps the nibbles sit at ph .. ph+15 of three words
-  const unsigned *bp = a.bases + (size_t)((r + 8) >> 3) * a.Np + n;
-  int4 buf[PF], far[PF];
-  if (!INIT)
-  {
-#pragma unroll
-    for (int i = 0; i < PF; i++) buf[i] = ld_stream(Sin + (size_t)(i < Q ? i : Q - 1) * 64);
-#pragma unroll
-    for (int i = 0; i < PF; i++) far[i] = ld_stream(Sin + (size_t)(i + PF < Q ? i + PF : Q - 1) * 64);
-  }
-  const int2 bd = a.bounds[n];
-  const unsigned w0 = bp[0], w1 = bp[(size_t)a.Np], w2 = bp[2 * (size_t)a.Np];
-
-  // ---- vote for row r, stop rule (every wave, redundantly; block 0 publishes) -------------
-  int besta = 0;
-  bool new_max = false;
-  if (!INIT)
-  {
-    long long v[4] = { 0, 0, 0, 0 };
-    if (lane < a.nshards_in)
-    {
-      const long long *p = a.sums_in + lane * 4;
-      v[0] = p[0]; v[1] = p[1]; v[2] = p[2]; v[3] = p[3];
-    }
-    const RamxCtl c = *a.ctl_in;
-    if (c.stopped)           // uniform: the host runs ahead of the device-side stop decision
-    {
-      if (blockIdx.x == 0 && threadIdx.x == 0) *a.ctl_out = c;   // keep both flip-flop slots stopped
-      return;
-    }
-    long long curr = 0;      // ram_extend.c:973-974
-    int ovf = c.overflow;
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-    {
-      v[k] = wave_sum_ll(v[k]);
-      if (v[k] > 2147483647LL || v[k] < -2147483648LL) ovf = 1;
-      if (v[k] > curr) { curr = v[k]; besta = k; }   // :1081-1085 strict >, ties -> lowest base
-    }
-    int dist = c.max_row - a.r;
-    dist = dist < 0 ? -dist : dist;
-    new_max = curr >= c.max_ext + (long long)dist * a.minimp;   // :1194-1196
-    const int max_row = new_max ? a.r : c.max_row;
-    const long long max_ext = new_max ? curr : c.max_ext;
-    int d2 = a.r - max_row;
-    d2 = d2 < 0 ? -d2 : d2;
-    if (blockIdx.x == 0 && threadIdx.x == 0)
-    {
-      RamxCtl o;
-      o.max_ext = max_ext; o.max_row = max_row; o.stopped = (d2 >= a.when_to_stop) ? 1 : 0;   // :1216
-      o.rows_done = a.r + 1; o.overflow = ovf; o.besta = besta; o.pad = 0;
-      *a.ctl_out = o;
-      a.cons_out[a.r] = (signed char)besta;   // :1092-1095 (host scatters into master[])
-    }
-  }
-  else if (blockIdx.x == 0 && threadIdx.x == 0)
-  {
-    RamxCtl o;
-    o.max_ext = 0; o.max_row = -1; o.stopped = 0; o.rows_done = 0; o.overflow = 0; o.besta = 0; o.pad = 0;
-    *a.ctl_out = o;
-  }
-  if (threadIdx.x < TAB_ROWS * TAB_STRIDE)
-  {
-    const int row = threadIdx.x / TAB_STRIDE, col = threadIdx.x % TAB_STRIDE;
-    int v = 0;
-    if (row < RAMX_NCLASS) v = (col < 4) ? a.tab[row][col] : (col == 4 ? a.tab[row][besta] : 0);
-    s_tab[threadIdx.x] = v;
-  }
-  if (blockIdx.x == 0)
-    for (int i = threadIdx.x; i < NSHARD * 4; i += BLOCK) a.sums_zero[i] = 0;
-  __syncthreads();
-
-  // ---- the band: one lane = one flank -----------------------------------------------------
-  int contrib[4] = { 0, 0, 0, 0 };              // each in [0, 2^31)
-  if (live)
-  {
-    const int jlo = bd.x - r, jhi = bd.y - r;        // cell j (row r) / j-1 (row r+1) is in bounds iff jlo <= j <= jhi
-    LaneDP D;
-    D.eC = NEG; D.mPrev = NEG - 1000000; D.bestF = NEG; D.jbest = 0;
-#pragma unroll
-    for (int c = 0; c < 4; c++) { D.eA[c] = NEG; D.bestA[c] = NEG; }
-    int high = 0, pos = 0;
-    // wave-uniform choice: do all 64 flanks cover every cell of both rows?  (steps 0..B)
-    const bool all_in = !INIT && __all((jlo <= 0) && (jhi >= B));
-    if (all_in) run_band<INIT, false, CHAIN>(a, r, s_tab, Sin, Sout, bp, jlo, jhi, D, high, pos, buf, far, w0, w1, w2);
-    else run_band<INIT, true, CHAIN>(a, r, s_tab, Sin, Sout, bp, jlo, jhi, D, high, pos, buf, far, w0, w1, w2);
-    if (INIT || new_max) a.trim[n] = make_int2(high, pos);   // ram_extend.c:1203-1207 (913-914 at init)
-    if (n < a.Nx)
-    {
-      const int capv = high + a.cap;
-#pragma unroll
-      for (int c = 0; c < 4; c++)
-      {
-        const int b = D.bestA[c] < 0 ? 0 : D.bestA[c];         // ram_extend.c:1042
-        contrib[c] = (b >= capv) ? b : capv;                   // :1052-1062
-      }
-    }
-  }
-
-  // ---- 64 lanes -> wave -> block -> one int64 atomic per candidate into this block's shard ----
-  {
-    long long tot[4];
-#pragma unroll
-    for (int c = 0; c < 4; c++) tot[c] = wave_sum_nonneg31(contrib[c]);
-    if (lane == 0)
-    {
-#pragma unroll
-      for (int c = 0; c < 4; c++) s_red[wave][c] = tot[c];
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x < 4)
-  {
-    long long t = 0;
-#pragma unroll
-    for (int wv = 0; wv < WPB; wv++) t += s_red[wv][threadIdx.x];
-    atomicAdd((unsigned long long *)(a.sums_out + (blockIdx.x % NSHARD) * 4 + threadIdx.x), (unsigned long long)t);
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// persistent kernel: the whole direction in ONE launch, DP rows resident in registers
-// ------------------------------------------------------------------------------------------
-//
-// For W known at compile time and N <= (resident waves) x 64 the row of a flank (2 x (2W+1) int32) fits the
-// lane's registers, so the row never travels: HBM sees only the base words (~12 words per flank per column) and
-// the 32-byte vote.  All L columns run inside one cooperative launch; the dependent-launch boundary of the
-// streaming kernel becomes a device-wide barrier that is fused with the vote:
-//
-//   column c, every block:   4 x int64 atomicAdd into shard (blockIdx % 32) of vote set (c+1) % 3.  Each add
-//                            carries its own arrival ticket: value = partial_sum + 2^41 + 2^54, so bits 54..63 of
-//                            a shard word count the blocks that have contributed and the low 54 bits hold
-//                            sum + count * 2^41 (|partial| <= 512 lanes * 2^31 < 2^41: exact for any input).
-//   column c+1, wave 0:      lanes 0..31 poll "their" shard's four words (relaxed agent-scope loads + s_sleep,
-//                            bounded) until all four show every block of the shard, decode, shuffle-reduce and
-//                            publish the vote through LDS.  One fabric round trip after the last arrival.
-//   Set (c+2) % 3 is zeroed by block 0 during column c, before block 0's own adds (everybody finished reading it
-//   before contributing to column c; nobody adds to it before block 0 itself has contributed to column c+1).
-//
-// Placement independent: only agent-scope atomics / atomic loads touch shared words, no assumption on which
-// XCD a block runs; co-residency is checked by hipLaunchCooperativeKernel and every spin is bounded (a timeout
-// raises `err` and every block leaves).  Multi-GPU runs keep the per-column launches (RCCL sits between them).
-
-struct PShard { unsigned long long word[4]; unsigned long long pad[4]; };   // 64 B: one cache line per shard
-#define PRK_BIAS (1ULL << 41)
-#define PRK_TICKET (1ULL << 54)
-
-// Multi-GPU: every rank owns one PeerBox in fine-grained device memory, mapped into all other ranks through
-// hipIpc handles.  After a rank's own blocks have all contributed to a column, its block 0 stores the rank's four
-// totals into slot [set][rank] of EVERY box (its own included) over xGMI; each word carries the column number in
-// its top 16 bits, so a reader knows a word is current without any flag or fence; every block then polls the local
-// box until all ranks' words of this column are there.  3 sets rotate exactly like the vote shards.
-#define RAMX_MAX_RANKS 16
-struct PeerBox { unsigned long long slot[3][RAMX_MAX_RANKS][4]; unsigned long long token[RAMX_MAX_RANKS]; };
-#define PEER_VBIAS (1LL << 46)
-#define PEER_VMASK ((1ULL << 48) - 1)
-
-struct PArgs
-{
-  int4 *S;                      // row state in HBM: read at start (boundary row from K(-1)), written back at the end
-  const unsigned *bases;
-  const int2 *bounds;
-  int2 *trim;
-  const long long *sums0;       // vote shards of row 0, produced by K(-1)
-  PShard *vote;                 // [3][NSHARD]
-  RamxCtl *ctl_out;
-  signed char *cons_out;
-  unsigned *err;                // != 0: a bounded spin gave up
-  PeerBox *const *peers;        // [nranks] every rank's box as seen from this device (NULL on one GPU)
-  PeerBox *box;                 // this rank's own box
-  int rank, nranks;
-  int Np, Nx, r0, L, go, ge, cap, minimp, when_to_stop, nblocks;
-  int tab[RAMX_NCLASS][4];
-  int pack_ok;                  // every reachable score fits 27 bits: the fast path may pack (score, cell) keys
-  unsigned long long *dbg;      // -DRAMX_PRK_TIMING builds only: [block][8] phase sums in 10 ns ticks
-};
-
-#define PRK_SPIN_LIMIT (1u << 22)
-#ifdef RAMX_PRK_TIMING
-#define PRK_TICK(k) do { const unsigned long long t_ = wall_clock64(); tsum[k] += t_ - tlast; tlast = t_; } while (0)
-#else
-#define PRK_TICK(k) do { } while (0)
-#endif
-
-// Row state of the persistent kernel: m[B] in registers; e is kept as the 16-bit difference d = e - m in LDS.
-// With go <= 0:  m + go + ge <= e <= m + ge  (e = max(sub+go, gap) + ge, m = max(sub, gap)), so d lies in
-// [go + ge, ge] and int16 is exact whenever go + ge >= -32768 (checked on the host).  Each lane owns one dword per
-// cell pair (layout [j/2][thread] dwords, halves by parity of j): conflict-free ds_read_i16 / ds_write_b16.
-#ifndef PRK_OOB_GROUP
-#define PRK_OOB_GROUP 2
-#endif
-#ifndef PRK_FAST_GROUP
-#define PRK_FAST_GROUP 8
-#endif
-#ifndef PRK_FETCH_AHEAD
-#define PRK_FETCH_AHEAD 2
-#endif
-__device__ __forceinline__ int vmax3(int x, int y, int z)   // forced v_max3_i32 (keeps the compiler from re-associating)
-{
-  int d;
-  asm("v_max3_i32 %0, %1, %2, %3" : "=v"(d) : "v"(x), "v"(y), "v"(z));
-  return d;
-}
-
-template <class F, int... Js>
-__device__ __forceinline__ void static_for(F &&f, std::integer_sequence<int, Js...>)
-{
-  (f(std::integral_constant<int, Js>{}), ...);
-}
-
-// Score table of the in-bounds fast path, addressed straight from the packed base stream with ONE SDWA instruction:
-// the eight nibbles of an aligned base word sit in four bytes; the LDS byte offset of the row of a class is
-// (byte & 0xF0) for the high nibble and (byte << 4) for the low nibble of a word whose high nibbles have been cleared
-// (one v_and per eight cells).  16 rows of 16 bytes: lanes reading the same class broadcast, different classes sit in
-// different banks.  A row is {M[A][b] | M[C][b] | M[G][b] | M[T][b] as four int8, M[besta][b], -, -}: one ds_read_b64
-// per cell; the candidates' scores are consumed by sign-extending SDWA adds.  Dword 1 is rewritten for every column
-// (the winner changes), by wave 0 / before a block barrier.  Requires every score in [-128, 127] (checked on the
-// host together with the key-packing bound).
-struct FastTabs
-{
-  int row[16][4];
-};
-
-template <int BYTE>
-__device__ __forceinline__ unsigned nib_lo_x16(unsigned A)   // ((A >> 8*BYTE) & 0xff) << 4
-{
-  unsigned d;
-  if (BYTE == 0) asm("v_lshlrev_b32_sdwa %0, 4, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(d) : "v"(A));
-  else if (BYTE == 1) asm("v_lshlrev_b32_sdwa %0, 4, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(d) : "v"(A));
-  else if (BYTE == 2) asm("v_lshlrev_b32_sdwa %0, 4, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(d) : "v"(A));
-  else asm("v_lshlrev_b32_sdwa %0, 4, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(d) : "v"(A));
-  return d;
-}
-template <int BYTE>
-__device__ __forceinline__ unsigned nib_hi_x16(unsigned A, unsigned mask_f0)   // (A >> 8*BYTE) & 0xf0
-{
-  unsigned d;
-  if (BYTE == 0) asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(d) : "s"(mask_f0), "v"(A));
-  else if (BYTE == 1) asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(d) : "s"(mask_f0), "v"(A));
-  else if (BYTE == 2) asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(d) : "s"(mask_f0), "v"(A));
-  else asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(d) : "s"(mask_f0), "v"(A));
-  return d;
-}
-
-template <int BYTE>
-__device__ __forceinline__ int add_sext_byte(int x, int packed)   // x + (int)(signed char)(packed >> 8*BYTE)
-{
-  int d;
-  if (BYTE == 0) asm("v_add_u32_sdwa %0, %1, sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(d) : "v"(x), "v"(packed));
-  else if (BYTE == 1) asm("v_add_u32_sdwa %0, %1, sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(d) : "v"(x), "v"(packed));
-  else if (BYTE == 2) asm("v_add_u32_sdwa %0, %1, sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(d) : "v"(x), "v"(packed));
-  else asm("v_add_u32_sdwa %0, %1, sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(d) : "v"(x), "v"(packed));
-  return d;
-}
-
-// candidate bytes: once per launch.
-template <int BLOCK>
-__device__ __forceinline__ void fast_tabs_init(FastTabs &ft, const int (&tab)[RAMX_NCLASS][4])
-{
-  if (threadIdx.x < 16)
-  {
-    const int cls = threadIdx.x;
-    unsigned pk = 0;
-    if (cls < RAMX_NCLASS)
-      pk = ((unsigned)tab[cls][0] & 0xffu) | (((unsigned)tab[cls][1] & 0xffu) << 8) | (((unsigned)tab[cls][2] & 0xffu) << 16) |
-           (((unsigned)tab[cls][3] & 0xffu) << 24);
-    ft.row[cls][0] = (int)pk; ft.row[cls][1] = 0; ft.row[cls][2] = 0; ft.row[cls][3] = 0;
-  }
-}
-// winner dword of the column whose winner is `besta` (threads 0..15 of the caller's group)
-__device__ __forceinline__ void fast_tabs_winner(FastTabs &ft, const int *tab_besta /* old-format table of besta */, int i)
-{
-  if (i < 16) ft.row[i][1] = i < RAMX_NCLASS ? tab_besta[i * TAB_STRIDE + 4] : 0;
-}
-
-// In-bounds, chain-free band of the register-resident kernels (the steady state of a run): per cell
-//   sub = Pm + sF;  m = max3(sub, eC, Pe);  e = max3(sub + go, eC, Pe) + ge          (5 VALU, chain of 2)
-// The four candidates take two cells per v_max3; their shared deletion term max_k e_k is folded in at the end.
-// The best cell of the row (value, lowest index on ties: bnw_extend.c:1020-1024) is tracked as a packed key
-// (m << 4) | (15 - (j & 15)) per 16-cell group, two cells per v_max3; exact while |m| < 2^27 (checked on the host).
-template <int W, int BLOCK>
-__device__ __forceinline__ void prk_band_fast(const int go, const int ge, const FastTabs &ft, short *sD, const int r,
-                                              const unsigned (&w)[(2 * W + 1 + 8) / 8 + 2], int (&M)[2 * W + 1], LaneDP &D)
-{
-  constexpr int B = 2 * W + 1, NG = (B + 15) / 16;
-  const int ph4 = 4 * ((r + 8) & 7);
-  const unsigned mask_f0 = 0xf0u;
-  short *myD = sD + 2 * threadIdx.x;
-  const char *tb = reinterpret_cast<const char *>(&ft.row[0][0]);
-  int eC = NEG, mPrev = NEG, maxE = NEG, ePend = NEG, kPend = NEG;
-  int bA[4] = { NEG, NEG, NEG, NEG }, pend[4] = { NEG, NEG, NEG, NEG };
-  int kg[NG];
-#pragma unroll
-  for (int g = 0; g < NG; g++) kg[g] = -2147483647 - 1;
-  // compile-time cell index: the band is generated step by step (no reliance on the loop unroller, whose size limit
-  // would otherwise leave the row in scratch memory).  Table rows and the previous row's e are fetched PD steps ahead
-  // of their use (a lone wave per SIMD -- one family per workgroup -- has nobody to hide the LDS latency behind).
-  constexpr int PD = PRK_FETCH_AHEAD;
-  unsigned A = 0, Alo = 0;
-  int2 rowQ[PD];                                    // {candidate bytes, M[besta][base]} of steps j .. j+PD-1
-  int dQ[PD];                                       // e - m of the previous row's cells j+1 .. j+PD
-  auto fetch_row = [&](auto jc) __attribute__((always_inline))
-  {
-    constexpr int jn = decltype(jc)::value;         // the step whose base is looked up
-    if constexpr ((jn & 7) == 0 || jn == 0)
-    {
-      A = __builtin_amdgcn_alignbit(w[(jn >> 3) + 1], w[jn >> 3], ph4);
-      Alo = A & 0x0f0f0f0fu;                        // low nibbles only: (byte << 4) is then the row offset of the class
-    }
-    constexpr int byte = (jn & 7) / 2;
-    unsigned off;
-    if constexpr ((jn & 1) == 0) off = nib_lo_x16<byte>(Alo);
-    else off = nib_hi_x16<byte>(A, mask_f0);
-    return *reinterpret_cast<const int2 *>(tb + off);
-  };
-  static_for([&](auto kc) __attribute__((always_inline))
-  {
-    constexpr int k = decltype(kc)::value;
-    if constexpr (k <= B) rowQ[k] = fetch_row(std::integral_constant<int, (k <= B ? k : 0)>{});
-    else rowQ[k] = make_int2(0, 0);
-    dQ[k] = (k + 1 < B) ? (int)myD[((k + 1) >> 1) * (2 * BLOCK) + ((k + 1) & 1)] : 0;
-  }, std::make_integer_sequence<int, PD>{});
-  auto step = [&](auto jc) __attribute__((always_inline))
-  {
-    constexpr int j = decltype(jc)::value;
-    if constexpr ((j & (PRK_FAST_GROUP - 1)) == 0)
-    {
-      // pin the accumulators to their group: nothing but data dependences orders pure arithmetic against
-      // sched_barrier during instruction selection, and a sunk accumulation keeps every table row alive
-      asm volatile("" ::"v"(bA[0]), "v"(bA[1]), "v"(bA[2]), "v"(bA[3]), "v"(maxE), "v"(kg[(j > 0 ? j - 1 : 0) >> 4]));
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    const int sv = rowQ[0].x, sF = rowQ[0].y;
-    const int dCur = dQ[0];
-#pragma unroll
-    for (int k = 0; k + 1 < PD; k++) { rowQ[k] = rowQ[k + 1]; dQ[k] = dQ[k + 1]; }
-    if constexpr (j + PD <= B) rowQ[PD - 1] = fetch_row(std::integral_constant<int, (j + PD <= B ? j + PD : 0)>{});
-    if constexpr (j + PD + 1 < B) dQ[PD - 1] = (int)myD[((j + PD + 1) >> 1) * (2 * BLOCK) + ((j + PD + 1) & 1)];
-    // candidates' cell j-1 of row r+1: substitution from m_{j-1} of row r (the base of that cell is this step's)
-    if constexpr (j >= 1)
-    {
-      const int t4[4] = { add_sext_byte<0>(mPrev, sv), add_sext_byte<1>(mPrev, sv), add_sext_byte<2>(mPrev, sv), add_sext_byte<3>(mPrev, sv) };
-      if constexpr ((j & 1) != 0)
-      {
-#pragma unroll
-        for (int c = 0; c < 4; c++) pend[c] = t4[c];
-      }
-      else
-      {
-#pragma unroll
-        for (int c = 0; c < 4; c++) bA[c] = imax3(bA[c], pend[c], t4[c]);
-      }
-    }
-    if constexpr (j < B)
-    {
-      const int Pm = M[j];
-      int Pe = NEG;
-      if constexpr (j + 1 < B) Pe = M[j + 1] + dCur;
-      const int sub = Pm + sF;                       // bnw_extend.c:950-956
-      const int m = vmax3(sub, eC, Pe);              // max(sub, max(ins, del)), :1007-1018
-      const int e = vmax3(sub + go, eC, Pe) + ge;
-      M[j] = m;
-      myD[(j >> 1) * (2 * BLOCK) + (j & 1)] = (short)(e - m);
-      const int key = (int)(((unsigned)m << 4) | (unsigned)(15 - (j & 15)));
-      if constexpr ((j & 1) == 0 && j + 1 < B) kPend = key;
-      else if constexpr ((j & 1) != 0) kg[j >> 4] = imax3(kg[j >> 4], kPend, key);
-      else kg[j >> 4] = imax(kg[j >> 4], key);
-      // deletion term of candidate cell j-1 is e_j (cells 1..B-1)
-      if constexpr (j >= 1)
-      {
-        if constexpr ((j & 1) != 0) ePend = e;
-        else maxE = imax3(maxE, ePend, e);
-      }
-      mPrev = m;
-      eC = e;
-    }
-  };
-  static_for(step, std::make_integer_sequence<int, B + 1>{});
-  // B is odd: the last candidate term (step B) is still pending; B-1 is even: every e has been folded
-#pragma unroll
-  for (int c = 0; c < 4; c++) D.bestA[c] = imax3(bA[c], (B & 1) ? pend[c] : NEG, maxE);
-  // best cell: highest value, lowest group on ties (inside a group the key already prefers the lowest cell)
-  int bestv = kg[NG - 1] >> 4, bkey = kg[NG - 1], bg = NG - 1;
-#pragma unroll
-  for (int g = NG - 2; g >= 0; g--)
-  {
-    const int v = kg[g] >> 4;
-    const bool take = v >= bestv;
-    bestv = take ? v : bestv;
-    bkey = take ? kg[g] : bkey;
-    bg = take ? g : bg;
-  }
-  D.bestF = bestv;
-  D.jbest = 16 * bg + 15 - (bkey & 15);
-}
-
-template <int W, bool OOB, int BLOCK, bool INIT = false>
-__device__ __forceinline__ void prk_band(const int go, const int ge, const int *s_tab, const FastTabs &ft, short *sD, const int r,
-                                         const unsigned (&w)[(2 * W + 1 + 8) / 8 + 2], const int jlo, const int jhi,
-                                         int (&M)[2 * W + 1], LaneDP &D)
-{
-  constexpr int B = 2 * W + 1;
-  if (!OOB && !INIT)
-  {
-    prk_band_fast<W, BLOCK>(go, ge, ft, sD, r, w, M, D);
-    return;
-  }
-  const int edgeF = (r < W) ? go + (r + 1) * ge : SENT;
-  const int edgeC = (r + 1 < W) ? go + (r + 2) * ge : SENT;
-  const int ph4 = 4 * ((r + 8) & 7);
-  short *myD = sD + 2 * threadIdx.x;
-#pragma unroll
-  for (int j = 0; j <= B; j++)
-  {
-    // the row itself occupies B registers: keep the scheduler from hoisting every table lookup of the fully
-    // unrolled band to the top.  This is the rarely taken masked path: small groups, lowest register pressure
-    if ((j & (PRK_OOB_GROUP - 1)) == 0) __builtin_amdgcn_sched_barrier(0);
-    const unsigned A = __builtin_amdgcn_alignbit(w[(j >> 3) + 1], w[j >> 3], ph4);
-    const unsigned bc = (A >> (4 * (j & 7))) & 15u;
-    StepU u;
-    u.j = j; u.first = (j == 0); u.hi = 2147483647;
-    u.vF = (j < W) ? edgeF : SENT;
-    u.vC = u.first ? NEG : ((j - 1 < W) ? edgeC : SENT);
-    const StepT t = fetch_step<OOB>(s_tab, bc, (j >= jlo) && (j <= jhi), j == 0);
-    if (j < B)
-    {
-      const int Pm = M[j];
-      int PeNext = NEG;
-      if (j + 1 < B) PeNext = M[j + 1] + (int)myD[((j + 1) >> 1) * (2 * BLOCK) + ((j + 1) & 1)];   // previous row's e of cell j+1
-      int m, e;
-      band_step<INIT, true, OOB, false>(go, ge, W, u, t, Pm, PeNext, D, m, e);
-      M[j] = m;
-      myD[(j >> 1) * (2 * BLOCK) + (j & 1)] = (short)(e - m);
-    }
-    else
-    {
-      int dm, de;
-      band_step<INIT, false, OOB, false>(go, ge, W, u, t, 0, 0, D, dm, de);
-    }
-  }
-}
-
-template <int W, int BLOCK>
-__global__ __launch_bounds__(BLOCK, 2) void ramx_persistent_kernel(const PArgs a)
-{
-  constexpr int B = 2 * W + 1, Q = W + 1, NW = (B + 8) / 8 + 2, WPB = BLOCK / 64, RS = 2 * BLOCK;   // RS: shorts per cell-pair row of sD
-  // one object, tables first: their LDS addresses must fit the 16-bit offset field of the ds_read that uses them
-  struct Smem
-  {
-    FastTabs ft;
-    int tab4[4][TAB_ROWS * TAB_STRIDE];                // one score table per winner base (masked path)
-    long long red[WPB][4];
-    long long vote[4];
-    int fail, pad[3];
-    short d[((B + 1) / 2) * RS];                       // d = e - m, [cell pair][thread][parity]
-  };
-  __shared__ __attribute__((aligned(16))) Smem sm;
-  FastTabs &s_ft = sm.ft;
-  int (&s_tab4)[4][TAB_ROWS * TAB_STRIDE] = sm.tab4;
-  long long (&s_red)[WPB][4] = sm.red;
-  long long (&s_vote)[4] = sm.vote;
-  int &s_fail = sm.fail;
-  short *sD = sm.d;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int tile = blockIdx.x * WPB + wave;
-  const bool live = tile < (a.Np >> 6);
-  const int n = (live ? tile : 0) * 64 + lane;
-  int4 *S = a.S + (size_t)(live ? tile : 0) * Q * 64 + lane;
-  short *myD = sD + 2 * threadIdx.x;
-
-  // ---- row state -> registers (m) and LDS (e - m) -----------------------------------------
-  int M[B];
-  int high, pos, thigh = 0, tpos = 0;
-  {
-#pragma unroll
-    for (int q = 0; q < W; q++)
-    {
-      const int4 v = S[(size_t)q * 64];
-      M[2 * q] = v.x; M[2 * q + 1] = v.z;
-      myD[q * RS] = (short)(v.y - v.x); myD[q * RS + 1] = (short)(v.w - v.z);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    const int4 v = S[(size_t)W * 64];
-    M[B - 1] = v.x; myD[W * RS] = (short)(v.y - v.x); high = v.z; pos = v.w;
-  }
-  const int2 bd = a.bounds[n];
-  const int shard = blockIdx.x % NSHARD;
-  const int my_shard_blocks = (a.nblocks - (lane & (NSHARD - 1)) + NSHARD - 1) / NSHARD;   // wave 0: blocks arriving on shard `lane & 31`
-
-  long long max_ext = 0;
-  int max_row = -1, rows_done = 0, ovf = 0, stopped = 0, failed = 0;
-  if (threadIdx.x == 0) s_fail = 0;
-  for (int i = threadIdx.x; i < 4 * TAB_ROWS * TAB_STRIDE; i += BLOCK)
-  {
-    const int bt = i / (TAB_ROWS * TAB_STRIDE), e = i % (TAB_ROWS * TAB_STRIDE), row = e / TAB_STRIDE, col = e % TAB_STRIDE;
-    int v = 0;
-    if (row < RAMX_NCLASS) v = (col < 4) ? a.tab[row][col] : (col == 4 ? a.tab[row][bt] : 0);
-    s_tab4[bt][e] = v;
-  }
-  fast_tabs_init<BLOCK>(s_ft, a.tab);
-  __syncthreads();
-
-#ifdef RAMX_PRK_TIMING
-  unsigned long long tsum[6] = { 0, 0, 0, 0, 0, 0 }, tlast = wall_clock64();
-#endif
-  for (int r = 0; r < a.L; r++)
-  {
-    PRK_TICK(5);
-    // ---- base words of this column (independent of the vote: issued before the wait) -------
-    unsigned w[NW];
-    {
-      const unsigned *bp = a.bases + (size_t)((r + 8) >> 3) * a.Np + n;
-#pragma unroll
-      for (int k = 0; k < NW; k++) w[k] = bp[(size_t)k * a.Np];
-    }
-    // ---- vote of row r -----------------------------------------------------------------------
-    if (wave == 0)
-    {
-      long long v[4] = { 0, 0, 0, 0 };
-      if (r == 0)
-      {
-        if (lane < NSHARD) { const long long *p = a.sums0 + lane * 4; v[0] = p[0]; v[1] = p[1]; v[2] = p[2]; v[3] = p[3]; }
-      }
-      else
-      {
-        // lane = shard + 32 * half polls words 2*half, 2*half+1 of "its" shard: one 16-byte load per lane and round
-        // (a quarter of the requests of four 8-byte loads on 32 lanes; the poll competes with the adds it waits for)
-        const int sidx = lane & (NSHARD - 1), half = lane >> 5;
-        const unsigned long long *src = &a.vote[(size_t)(r % 3) * NSHARD + sidx].word[2 * half];
-        unsigned spins = 0;
-        bool done = my_shard_blocks <= 0 || (a.nranks > 1 && blockIdx.x != 0);   // multi-rank: only the exchanger needs the local total
-        unsigned long long x0 = 0, x1 = 0;
-        for (;;)
-        {
-          if (!done)
-          {
-            typedef unsigned v4u __attribute__((ext_vector_type(4)));
-            v4u q;
-            asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(q) : "v"(src) : "memory");
-            x0 = ((unsigned long long)q.y << 32) | q.x;
-            x1 = ((unsigned long long)q.w << 32) | q.z;
-            done = (x0 >> 54) >= (unsigned long long)my_shard_blocks && (x1 >> 54) >= (unsigned long long)my_shard_blocks;
-          }
-          if (__all(done)) break;
-          if (++spins > PRK_SPIN_LIMIT || ((spins & 1023u) == 0 && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0))
-          {
-            failed = 1;
-            break;
-          }
-          __builtin_amdgcn_s_sleep(1);
-        }
-        long long y0 = 0, y1 = 0;
-        if (my_shard_blocks > 0 && !failed && !(a.nranks > 1 && blockIdx.x != 0))
-        {
-          y0 = (long long)(x0 & (PRK_TICKET - 1)) - (long long)(x0 >> 54) * (long long)PRK_BIAS;
-          y1 = (long long)(x1 & (PRK_TICKET - 1)) - (long long)(x1 >> 54) * (long long)PRK_BIAS;
-        }
-        // fold the 32 shards inside each half-wave; lanes 0 / 32 end up with words {0,1} / {2,3}
-#pragma unroll
-        for (int m = 16; m >= 1; m >>= 1) { y0 += __shfl_xor(y0, m, 64); y1 += __shfl_xor(y1, m, 64); }
-        v[0] = __shfl(y0, 0, 64); v[1] = __shfl(y1, 0, 64); v[2] = __shfl(y0, 32, 64); v[3] = __shfl(y1, 32, 64);
-      }
-      if (r == 0)
-      {
-#pragma unroll
-        for (int k = 0; k < 4; k++) v[k] = wave_sum_ll(v[k]);
-      }
-      if (a.nranks > 1 && r > 0 && !failed)
-      {
-        // ---- cross-device step: v[] is this rank's total (identical in all lanes) -----------
-        const unsigned long long tag = (unsigned long long)(r & 0xffff) << 48;
-        if (blockIdx.x == 0 && lane < a.nranks)
-        {
-          PeerBox *pb = a.peers[lane];
-#pragma unroll
-          for (int k = 0; k < 4; k++)
-          {
-            if (v[k] >= PEER_VBIAS || v[k] <= -PEER_VBIAS) failed = 1;     // cannot be encoded: fail loudly
-            __hip_atomic_store(&pb->slot[r % 3][a.rank][k], tag | ((unsigned long long)(v[k] + PEER_VBIAS) & PEER_VMASK),
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-          }
-        }
-        unsigned long long y[4] = { 0, 0, 0, 0 };
-        bool got = lane >= a.nranks;
-        unsigned spins = 0;
-        for (;;)
-        {
-          if (!got)
-          {
-#pragma unroll
-            for (int k = 0; k < 4; k++) y[k] = __hip_atomic_load(&a.box->slot[r % 3][lane][k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            got = (y[0] >> 48) == (tag >> 48) && (y[1] >> 48) == (tag >> 48) && (y[2] >> 48) == (tag >> 48) && (y[3] >> 48) == (tag >> 48);
-          }
-          if (__all(got)) break;
-          if (++spins > PRK_SPIN_LIMIT || ((spins & 1023u) == 0 && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0))
-          {
-            failed = 1;
-            break;
-          }
-          __builtin_amdgcn_s_sleep(1);
-        }
-        failed = __any(failed) ? 1 : 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-          v[k] = wave_sum_ll((lane < a.nranks && !failed) ? (long long)(y[k] & PEER_VMASK) - PEER_VBIAS : 0LL);
-      }
-      {
-        // the winner's substitution column of the fast-path tables (same argmax rule as below, ram_extend.c:1064-1086)
-        long long cw = 0;
-        int bw = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-          if (v[k] > cw) { cw = v[k]; bw = k; }
-        fast_tabs_winner(s_ft, s_tab4[bw], lane);
-      }
-      if (lane == 0)
-      {
-        s_vote[0] = v[0]; s_vote[1] = v[1]; s_vote[2] = v[2]; s_vote[3] = v[3];
-        s_fail = failed;
-        if (failed) __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
-    PRK_TICK(0);                 // wave 0: vote seen (other waves: nothing)
-    __syncthreads();
-    PRK_TICK(1);                 // released by the block barrier
-    if (__builtin_amdgcn_readfirstlane(s_fail)) { failed = 1; break; }
-    long long curr = 0;
-    int besta = 0;
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-    {
-      // the vote is wave-uniform: move it to scalar registers so that the whole stop rule runs on the SALU and
-      // none of its state (max_ext, max_row, ...) occupies vector registers next to the row
-      const long long vv = s_vote[k];
-      const long long vk = ((long long)__builtin_amdgcn_readfirstlane((int)(vv >> 32)) << 32) |
-                           (long long)(unsigned)__builtin_amdgcn_readfirstlane((int)vv);
-      if (vk > 2147483647LL || vk < -2147483648LL) ovf = 1;
-      if (vk > curr) { curr = vk; besta = k; }
-    }
-    int dist = max_row - r;
-    dist = dist < 0 ? -dist : dist;
-    const bool new_max = curr >= max_ext + (long long)dist * a.minimp;
-    if (new_max) { max_row = r; max_ext = curr; }
-    int d2 = r - max_row;
-    d2 = d2 < 0 ? -d2 : d2;
-    stopped = d2 >= a.when_to_stop;
-    rows_done = r + 1;
-    if (blockIdx.x == 0 && threadIdx.x == 0) a.cons_out[r] = (signed char)besta;
-    // block 0 clears the vote set of row r+2 (see the protocol above)
-    if (blockIdx.x == 0 && threadIdx.x < NSHARD)
-    {
-      PShard *z = a.vote + (size_t)((r + 2) % 3) * NSHARD + threadIdx.x;
-#pragma unroll
-      for (int k = 0; k < 4; k++) __hip_atomic_store(&z->word[k], 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    const int *s_tab = s_tab4[besta];                // column 4 of table `besta` holds M[besta][class]
-
-    // ---- the band, rows in registers ---------------------------------------------------------
-    int contrib[4] = { 0, 0, 0, 0 };       // each in [0, 2^31): clamped at 0 below, capped from below by high + cap
-    if (live)
-    {
-      const int jlo = bd.x - r, jhi = bd.y - r;
-      LaneDP D;
-      D.eC = NEG; D.mPrev = NEG - 1000000; D.bestF = NEG; D.jbest = 0;
-#pragma unroll
-      for (int c = 0; c < 4; c++) { D.eA[c] = NEG; D.bestA[c] = NEG; }
-      const bool all_in = a.pack_ok && __all((jlo <= 0) && (jhi >= B));
-      if (all_in) prk_band<W, false, BLOCK>(a.go, a.ge, s_tab, s_ft, sD, r, w, jlo, jhi, M, D);
-      else prk_band<W, true, BLOCK>(a.go, a.ge, s_tab, s_ft, sD, r, w, jlo, jhi, M, D);
-      if (D.bestF > high) { high = D.bestF; pos = r + D.jbest - W; }   // ram_extend.c:1140-1150
-      if (new_max) { thigh = high; tpos = pos; }                        // :1203-1207
-      if (n < a.Nx)
-      {
-        const int capv = high + a.cap;
-#pragma unroll
-        for (int c = 0; c < 4; c++)
-        {
-          const int b = D.bestA[c] < 0 ? 0 : D.bestA[c];
-          contrib[c] = (b >= capv) ? b : capv;
-        }
-      }
-    }
-    PRK_TICK(2);                 // band done
-    if (stopped || r == a.L - 1) break;     // the vote of row r+1 will not be consumed
-    {
-      long long tot[4];
-#pragma unroll
-      for (int c = 0; c < 4; c++) tot[c] = wave_sum_nonneg31(contrib[c]);
-      if (lane == 0)
-      {
-#pragma unroll
-        for (int c = 0; c < 4; c++) s_red[wave][c] = tot[c];
-      }
-    }
-    __syncthreads();
-    PRK_TICK(3);                 // wave reduction + block barrier
-    if (blockIdx.x == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // block 0: its zeroing stores first
-    if (threadIdx.x < 4)
-    {
-      long long t = 0;
-#pragma unroll
-      for (int wv = 0; wv < WPB; wv++) t += s_red[wv][threadIdx.x];
-      PShard *sh = a.vote + (size_t)((r + 1) % 3) * NSHARD + shard;
-      __hip_atomic_fetch_add(&sh->word[threadIdx.x], (unsigned long long)t + PRK_BIAS + PRK_TICKET, __ATOMIC_RELAXED,
-                             __HIP_MEMORY_SCOPE_AGENT);
-    }
-    PRK_TICK(4);                 // contribution issued
-  }
-#ifdef RAMX_PRK_TIMING
-  if (a.dbg != NULL && (threadIdx.x & 63) == 0)
-  {
-#pragma unroll
-    for (int k = 0; k < 6; k++) a.dbg[((size_t)blockIdx.x * WPB + wave) * 8 + k] = tsum[k];
-  }
-#endif
-
-  // ---- write back: rows (so that the device state can be inspected / resumed), trim, control ----
-  if (live)
-  {
-#pragma unroll
-    for (int q = 0; q < W; q++)
-    {
-      S[(size_t)q * 64] = make_int4(M[2 * q], M[2 * q] + (int)myD[q * RS], M[2 * q + 1], M[2 * q + 1] + (int)myD[q * RS + 1]);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    S[(size_t)W * 64] = make_int4(M[B - 1], M[B - 1] + (int)myD[W * RS], high, pos);
-    a.trim[n] = make_int2(thigh, tpos);
-  }
-  if (blockIdx.x == 0 && threadIdx.x == 0)
-  {
-    RamxCtl o;
-    o.max_ext = max_ext; o.max_row = max_row; o.stopped = stopped; o.rows_done = rows_done; o.overflow = ovf; o.besta = 0;
-    o.pad = failed;
-    *a.ctl_out = o;
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// batch mode: one BLOCK = one family
-// ------------------------------------------------------------------------------------------
-//
-// Real inputs are hundreds of families of ~100 flanks each (util/extend-stk.pl runs one RAMExtend process per
-// family).  A family of up to BLOCK flanks fits one workgroup, so its per-column vote is a block-local LDS
-// reduction: no device-wide barrier, no atomics, no cooperative launch, any number of families per launch (blocks
-// that are not resident simply wait their turn), each family stopping on its own fit-preferred rule.  Rows live in
-// registers / LDS exactly as in the persistent kernel; the boundary row and the candidates of row 0 are produced
-// in-kernel (column "-1").
-
-struct FamDesc { int tile0, ntiles, nx, id; };      // first 64-flank tile, tiles, flanks of the family; its index in the caller's arrays
-
-struct FArgs
-{
-  const unsigned *bases;
-  const int2 *bounds;
-  const FamDesc *fam;
-  int2 *trim;                   // per flank
-  RamxCtl *ctl_out;             // per family
-  signed char *cons_out;        // [family][L]
-  int Np, L, go, ge, cap, minimp, when_to_stop;
-  int tab[RAMX_NCLASS][4];
-  int pack_ok;
-};
-
-template <int W, int BLOCK>
-__global__ __launch_bounds__(BLOCK, 2) void ramx_family_kernel(const FArgs a)
-{
-  constexpr int B = 2 * W + 1, NW = (B + 8) / 8 + 2, WPB = BLOCK / 64, RS = 2 * BLOCK;
-  struct Smem     // tables first (16-bit ds offsets), see the persistent kernel
-  {
-    FastTabs ft;
-    int tab4[4][TAB_ROWS * TAB_STRIDE];
-    long long red[2][WPB][4];
-    short d[((B + 1) / 2) * RS];
-  };
-  __shared__ __attribute__((aligned(16))) Smem sm;
-  FastTabs &s_ft = sm.ft;
-  int (&s_tab4)[4][TAB_ROWS * TAB_STRIDE] = sm.tab4;
-  long long (&s_red)[2][WPB][4] = sm.red;
-  short *sD = sm.d;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const FamDesc fd = a.fam[blockIdx.x];
-  const int vwave = wave;
-  const bool live = vwave < fd.ntiles;
-  const int n = (fd.tile0 + (live ? vwave : 0)) * 64 + lane;
-  const bool active = live && (vwave * 64 + lane) < fd.nx;
-
-  for (int i = threadIdx.x; i < 4 * TAB_ROWS * TAB_STRIDE; i += BLOCK)
-  {
-    const int bt = i / (TAB_ROWS * TAB_STRIDE), e = i % (TAB_ROWS * TAB_STRIDE), row = e / TAB_STRIDE, col = e % TAB_STRIDE;
-    int v = 0;
-    if (row < RAMX_NCLASS) v = (col < 4) ? a.tab[row][col] : (col == 4 ? a.tab[row][bt] : 0);
-    s_tab4[bt][e] = v;
-  }
-  fast_tabs_init<BLOCK>(s_ft, a.tab);
-  __syncthreads();
-
-  int M[B];
-#pragma unroll
-  for (int j = 0; j < B; j++) M[j] = 0;
-  int high = 0, pos = 0, thigh = 0, tpos = 0;
-  const int2 bd = a.bounds[n];
-  long long max_ext = 0;
-  int max_row = -1, rows_done = 0, ovf = 0, stopped = 0;
-
-  // base words of the lane's window: the window moves by one nibble per column, so the words are carried across
-  // columns and ONE new word is loaded every eighth column (its first use is at the far end of the band)
-  unsigned w[NW];
-  {
-    const unsigned *bp = a.bases + n;               // column -1 starts at word (r + 8) >> 3 = 0
-#pragma unroll
-    for (int k = 0; k < NW; k++) w[k] = bp[(size_t)k * a.Np];
-  }
-  for (int r = -1; r < a.L; r++)
-  {
-    if (r >= 0 && ((r + 8) & 7) == 0)
-    {
-#pragma unroll
-      for (int k = 0; k + 1 < NW; k++) w[k] = w[k + 1];
-      w[NW - 1] = a.bases[(size_t)(((r + 8) >> 3) + NW - 1) * a.Np + n];
-    }
-    int besta = 0;
-    bool new_max = false;
-    if (r >= 0)
-    {
-      // vote of row r: block-local (written at the end of the previous iteration, double buffered)
-      long long curr = 0;
-#pragma unroll
-      for (int k = 0; k < 4; k++)
-      {
-        long long vv = 0;
-#pragma unroll
-        for (int wv = 0; wv < WPB; wv++) vv += s_red[r & 1][wv][k];
-        // wave-uniform: keep the vote and the stop rule on the scalar unit (see the persistent kernel)
-        const long long vk = ((long long)__builtin_amdgcn_readfirstlane((int)(vv >> 32)) << 32) |
-                             (long long)(unsigned)__builtin_amdgcn_readfirstlane((int)vv);
-        if (vk > 2147483647LL || vk < -2147483648LL) ovf = 1;
-        if (vk > curr) { curr = vk; besta = k; }
-      }
-      int dist = max_row - r;
-      dist = dist < 0 ? -dist : dist;
-      new_max = curr >= max_ext + (long long)dist * a.minimp;
-      if (new_max) { max_row = r; max_ext = curr; }
-      int d2 = r - max_row;
-      d2 = d2 < 0 ? -d2 : d2;
-      stopped = d2 >= a.when_to_stop;
-      rows_done = r + 1;
-      if (threadIdx.x == 0) a.cons_out[(size_t)fd.id * a.L + r] = (signed char)besta;
-    }
-    const int *s_tab = s_tab4[besta];
-    if (r >= 0 && a.pack_ok)
-    {
-      // winner rows of the fast-path tables; everybody has left the previous column's band (barrier at its end)
-      fast_tabs_winner(s_ft, s_tab, threadIdx.x);
-      __syncthreads();
-    }
-    int contrib[4] = { 0, 0, 0, 0 };
-    if (live)
-    {
-      const int jlo = bd.x - r, jhi = bd.y - r;
-      LaneDP D;
-      D.eC = NEG; D.mPrev = NEG - 1000000; D.bestF = NEG; D.jbest = 0;
-#pragma unroll
-      for (int c = 0; c < 4; c++) { D.eA[c] = NEG; D.bestA[c] = NEG; }
-      if (r < 0)
-        prk_band<W, true, BLOCK, true>(a.go, a.ge, s_tab, s_ft, sD, r, w, jlo, jhi, M, D);
-      else
-      {
-        const bool all_in = a.pack_ok && __all((jlo <= 0) && (jhi >= B));
-        if (all_in) prk_band<W, false, BLOCK>(a.go, a.ge, s_tab, s_ft, sD, r, w, jlo, jhi, M, D);
-        else prk_band<W, true, BLOCK>(a.go, a.ge, s_tab, s_ft, sD, r, w, jlo, jhi, M, D);
-        if (D.bestF > high) { high = D.bestF; pos = r + D.jbest - W; }
-        if (new_max) { thigh = high; tpos = pos; }
-      }
-      if (active)
-      {
-        const int capv = high + a.cap;
-#pragma unroll
-        for (int c = 0; c < 4; c++)
-        {
-          const int b = D.bestA[c] < 0 ? 0 : D.bestA[c];
-          contrib[c] = (b >= capv) ? b : capv;
-        }
-      }
-    }
-    if (stopped || r == a.L - 1) break;
-    {
-      long long tot[4];
-#pragma unroll
-      for (int c = 0; c < 4; c++) tot[c] = wave_sum_nonneg31(contrib[c]);
-      if (lane == 0)
-      {
-#pragma unroll
-        for (int c = 0; c < 4; c++) s_red[(r + 1) & 1][wave][c] = tot[c];
-      }
-    }
-    __syncthreads();
-  }
-  if (live) a.trim[n] = make_int2(thigh, tpos);
-  if (threadIdx.x == 0)
-  {
-    RamxCtl o;
-    o.max_ext = max_ext; o.max_row = max_row; o.stopped = stopped; o.rows_done = rows_done; o.overflow = ovf; o.besta = 0; o.pad = 0;
-    a.ctl_out[fd.id] = o;
-  }
-}
-
-// Batch mode for everything the register-resident family kernel cannot take (any band width, positive penalties):
-// the same one-workgroup-per-family loop with a block-local vote, but the rows stream through the family's slice of
-// the in-place row buffer exactly as in ramx_column_kernel (run_band: runtime W, prefetch rings, CHAIN variant).  A
-// lane only ever reads state it wrote itself, so no cross-lane visibility is needed between columns; a family's rows
-// (W = 80, 100 flanks: 260 KB) stay in L2.
-struct FSArgs
-{
-  KArgs k;                      // bases, bounds, trim, S_in == S_out, Np, W, go, ge, cap, minimp, when_to_stop, tab
-  const FamDesc *fam;
-  RamxCtl *ctl_out;             // per family
-  signed char *cons_out;        // [family][L]
-  int L;
-};
-
-template <bool CHAIN, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void ramx_family_stream_kernel(const FSArgs fa)
-{
-  constexpr int WPB = BLOCK / 64;
-  __shared__ __attribute__((aligned(16))) int s_tab[TAB_ROWS * TAB_STRIDE];
-  __shared__ long long s_red[2][WPB][4];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const FamDesc fd = fa.fam[blockIdx.x];
-  const bool live = wave < fd.ntiles;
-  const int tile = fd.tile0 + (live ? wave : 0);
-  const int n = tile * 64 + lane;
-  const bool active = live && (wave * 64 + lane) < fd.nx;
-  const KArgs &a = fa.k;
-  const int W = a.W, B = 2 * W + 1, Q = W + 1;
-  const int4 *Sin = a.S_in + (size_t)tile * Q * 64 + lane;
-  int4 *Sout = a.S_out + (size_t)tile * Q * 64 + lane;
-  const int2 bd = a.bounds[n];
-  long long max_ext = 0;
-  int max_row = -1, rows_done = 0, ovf = 0, stopped = 0;
-
-  for (int r = -1; r < fa.L; r++)
-  {
-    const unsigned *bp = a.bases + (size_t)((r + 8) >> 3) * a.Np + n;
-    int4 buf[PF], far[PF];
-    if (r >= 0)
-    {
-#pragma unroll
-      for (int i = 0; i < PF; i++) buf[i] = ld_stream(Sin + (size_t)(i < Q ? i : Q - 1) * 64);
-#pragma unroll
-      for (int i = 0; i < PF; i++) far[i] = ld_stream(Sin + (size_t)(i + PF < Q ? i + PF : Q - 1) * 64);
-    }
-    const unsigned w0 = bp[0], w1 = bp[(size_t)a.Np], w2 = bp[2 * (size_t)a.Np];
-    int besta = 0;
-    bool new_max = false;
-    if (r >= 0)
-    {
-      long long curr = 0;
-#pragma unroll
-      for (int k = 0; k < 4; k++)
-      {
-        long long vk = 0;
-#pragma unroll
-        for (int wv = 0; wv < WPB; wv++) vk += s_red[r & 1][wv][k];
-        if (vk > 2147483647LL || vk < -2147483648LL) ovf = 1;
-        if (vk > curr) { curr = vk; besta = k; }
-      }
-      int dist = max_row - r;
-      dist = dist < 0 ? -dist : dist;
-      new_max = curr >= max_ext + (long long)dist * a.minimp;
-      if (new_max) { max_row = r; max_ext = curr; }
-      int d2 = r - max_row;
-      d2 = d2 < 0 ? -d2 : d2;
-      stopped = d2 >= a.when_to_stop;
-      rows_done = r + 1;
-      if (threadIdx.x == 0) fa.cons_out[(size_t)fd.id * fa.L + r] = (signed char)besta;
-    }
-    // the winner's score table; everybody has left the previous column's band (barrier at its end)
-    for (int i = threadIdx.x; i < TAB_ROWS * TAB_STRIDE; i += BLOCK)      // BLOCK may be 64: fewer threads than entries
-    {
-      const int row = i / TAB_STRIDE, col = i % TAB_STRIDE;
-      int v = 0;
-      if (row < RAMX_NCLASS) v = (col < 4) ? a.tab[row][col] : (col == 4 ? a.tab[row][besta] : 0);
-      s_tab[i] = v;
-    }
-    __syncthreads();
-    int contrib[4] = { 0, 0, 0, 0 };
-    if (live)
-    {
-      const int jlo = bd.x - r, jhi = bd.y - r;
-      LaneDP D;
-      D.eC = NEG; D.mPrev = NEG - 1000000; D.bestF = NEG; D.jbest = 0;
-#pragma unroll
-      for (int c = 0; c < 4; c++) { D.eA[c] = NEG; D.bestA[c] = NEG; }
-      int high = 0, pos = 0;
-      if (r < 0)
-        run_band<true, true, CHAIN>(a, r, s_tab, Sin, Sout, bp, jlo, jhi, D, high, pos, buf, far, w0, w1, w2);
-      else
-      {
-        const bool all_in = __all((jlo <= 0) && (jhi >= B));
-        if (all_in) run_band<false, false, CHAIN>(a, r, s_tab, Sin, Sout, bp, jlo, jhi, D, high, pos, buf, far, w0, w1, w2);
-        else run_band<false, true, CHAIN>(a, r, s_tab, Sin, Sout, bp, jlo, jhi, D, high, pos, buf, far, w0, w1, w2);
-      }
-      if (r < 0 || new_max) a.trim[n] = make_int2(high, pos);
-      if (active)
-      {
-        const int capv = high + a.cap;
-#pragma unroll
-        for (int c = 0; c < 4; c++)
-        {
-          const int b = D.bestA[c] < 0 ? 0 : D.bestA[c];
-          contrib[c] = (b >= capv) ? b : capv;
-        }
-      }
-    }
-    if (stopped || r == fa.L - 1) break;
-    {
-      long long tot[4];
-#pragma unroll
-      for (int c = 0; c < 4; c++) tot[c] = wave_sum_nonneg31(contrib[c]);
-      if (lane == 0)
-      {
-#pragma unroll
-        for (int c = 0; c < 4; c++) s_red[(r + 1) & 1][wave][c] = tot[c];
-      }
-    }
-    __syncthreads();
-  }
-  if (threadIdx.x == 0)
-  {
-    RamxCtl o;
-    o.max_ext = max_ext; o.max_row = max_row; o.stopped = stopped; o.rows_done = rows_done; o.overflow = ovf; o.besta = 0; o.pad = 0;
-    fa.ctl_out[fd.id] = o;
-  }
 }
 
 // ------------------------------------------------------------------------------------------

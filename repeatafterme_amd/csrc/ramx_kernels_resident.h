@@ -1,0 +1,791 @@
+// ramx_kernels_resident.h -- register-resident kernels: the device-wide persistent kernel and the one-workgroup-per-family kernel
+// (device code of libramx; included by ramx_device.hip only -- one translation unit so that everything inlines)
+#pragma once
+
+#include "ramx_kernels_common.h"
+
+// ------------------------------------------------------------------------------------------
+// persistent kernel: the whole direction in ONE launch, DP rows resident in registers
+// ------------------------------------------------------------------------------------------
+//
+// For W known at compile time and N <= (resident waves) x 64 the row of a flank (2 x (2W+1) int32) fits the
+// lane's registers, so the row never travels: HBM sees only the base words (~12 words per flank per column) and
+// the 32-byte vote.  All L columns run inside one cooperative launch; the dependent-launch boundary of the
+// streaming kernel becomes a device-wide barrier that is fused with the vote:
+//
+//   column c, every block:   4 x int64 atomicAdd into shard (blockIdx % 32) of vote set (c+1) % 3.  Each add
+//                            carries its own arrival ticket: value = partial_sum + 2^41 + 2^54, so bits 54..63 of
+//                            a shard word count the blocks that have contributed and the low 54 bits hold
+//                            sum + count * 2^41 (|partial| <= 512 lanes * 2^31 < 2^41: exact for any input).
+//   column c+1, wave 0:      lanes 0..31 poll "their" shard's four words (relaxed agent-scope loads + s_sleep,
+//                            bounded) until all four show every block of the shard, decode, shuffle-reduce and
+//                            publish the vote through LDS.  One fabric round trip after the last arrival.
+//   Set (c+2) % 3 is zeroed by block 0 during column c, before block 0's own adds (everybody finished reading it
+//   before contributing to column c; nobody adds to it before block 0 itself has contributed to column c+1).
+//
+// Placement independent: only agent-scope atomics / atomic loads touch shared words, no assumption on which
+// XCD a block runs; co-residency is checked by hipLaunchCooperativeKernel and every spin is bounded (a timeout
+// raises `err` and every block leaves).  Multi-GPU runs keep the per-column launches (RCCL sits between them).
+
+struct PShard { unsigned long long word[4]; unsigned long long pad[4]; };   // 64 B: one cache line per shard
+#define PRK_BIAS (1ULL << 41)
+#define PRK_TICKET (1ULL << 54)
+
+// Multi-GPU: every rank owns one PeerBox in fine-grained device memory, mapped into all other ranks through
+// hipIpc handles.  After a rank's own blocks have all contributed to a column, its block 0 stores the rank's four
+// totals into slot [set][rank] of EVERY box (its own included) over xGMI; each word carries the column number in
+// its top 16 bits, so a reader knows a word is current without any flag or fence; every block then polls the local
+// box until all ranks' words of this column are there.  3 sets rotate exactly like the vote shards.
+#define RAMX_MAX_RANKS 16
+struct PeerBox { unsigned long long slot[3][RAMX_MAX_RANKS][4]; unsigned long long token[RAMX_MAX_RANKS]; };
+#define PEER_VBIAS (1LL << 46)
+#define PEER_VMASK ((1ULL << 48) - 1)
+
+struct PArgs
+{
+  int4 *S;                      // row state in HBM: read at start (boundary row from K(-1)), written back at the end
+  const unsigned *bases;
+  const int2 *bounds;
+  int2 *trim;
+  const long long *sums0;       // vote shards of row 0, produced by K(-1)
+  PShard *vote;                 // [3][NSHARD]
+  RamxCtl *ctl_out;
+  signed char *cons_out;
+  unsigned *err;                // != 0: a bounded spin gave up
+  PeerBox *const *peers;        // [nranks] every rank's box as seen from this device (NULL on one GPU)
+  PeerBox *box;                 // this rank's own box
+  int rank, nranks;
+  int Np, Nx, r0, L, go, ge, cap, minimp, when_to_stop, nblocks;
+  int tab[RAMX_NCLASS][4];
+  int pack_ok;                  // every reachable score fits 27 bits: the fast path may pack (score, cell) keys
+  unsigned long long *dbg;      // -DRAMX_PRK_TIMING builds only: [block][8] phase sums in 10 ns ticks
+};
+
+#define PRK_SPIN_LIMIT (1u << 22)
+#ifdef RAMX_PRK_TIMING
+#define PRK_TICK(k) do { const unsigned long long t_ = wall_clock64(); tsum[k] += t_ - tlast; tlast = t_; } while (0)
+#else
+#define PRK_TICK(k) do { } while (0)
+#endif
+
+// Row state of the persistent kernel: m[B] in registers; e is kept as the 16-bit difference d = e - m in LDS.
+// With go <= 0:  m + go + ge <= e <= m + ge  (e = max(sub+go, gap) + ge, m = max(sub, gap)), so d lies in
+// [go + ge, ge] and int16 is exact whenever go + ge >= -32768 (checked on the host).  Each lane owns one dword per
+// cell pair (layout [j/2][thread] dwords, halves by parity of j): conflict-free ds_read_i16 / ds_write_b16.
+#ifndef PRK_OOB_GROUP
+#define PRK_OOB_GROUP 2
+#endif
+#ifndef PRK_FAST_GROUP
+#define PRK_FAST_GROUP 8
+#endif
+#ifndef PRK_FETCH_AHEAD
+#define PRK_FETCH_AHEAD 2
+#endif
+__device__ __forceinline__ int vmax3(int x, int y, int z)   // forced v_max3_i32 (keeps the compiler from re-associating)
+{
+  int d;
+  asm("v_max3_i32 %0, %1, %2, %3" : "=v"(d) : "v"(x), "v"(y), "v"(z));
+  return d;
+}
+
+template <class F, int... Js>
+__device__ __forceinline__ void static_for(F &&f, std::integer_sequence<int, Js...>)
+{
+  (f(std::integral_constant<int, Js>{}), ...);
+}
+
+// Score table of the in-bounds fast path, addressed straight from the packed base stream with ONE SDWA instruction:
+// the eight nibbles of an aligned base word sit in four bytes; the LDS byte offset of the row of a class is
+// (byte & 0xF0) for the high nibble and (byte << 4) for the low nibble of a word whose high nibbles have been cleared
+// (one v_and per eight cells).  16 rows of 16 bytes: lanes reading the same class broadcast, different classes sit in
+// different banks.  A row is {M[A][b] | M[C][b] | M[G][b] | M[T][b] as four int8, M[besta][b], -, -}: one ds_read_b64
+// per cell; the candidates' scores are consumed by sign-extending SDWA adds.  Dword 1 is rewritten for every column
+// (the winner changes), by wave 0 / before a block barrier.  Requires every score in [-128, 127] (checked on the
+// host together with the key-packing bound).
+struct FastTabs
+{
+  int row[16][4];
+};
+
+template <int BYTE>
+__device__ __forceinline__ unsigned nib_lo_x16(unsigned A)   // ((A >> 8*BYTE) & 0xff) << 4
+{
+  unsigned d;
+  if (BYTE == 0) asm("v_lshlrev_b32_sdwa %0, 4, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(d) : "v"(A));
+  else if (BYTE == 1) asm("v_lshlrev_b32_sdwa %0, 4, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(d) : "v"(A));
+  else if (BYTE == 2) asm("v_lshlrev_b32_sdwa %0, 4, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(d) : "v"(A));
+  else asm("v_lshlrev_b32_sdwa %0, 4, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(d) : "v"(A));
+  return d;
+}
+template <int BYTE>
+__device__ __forceinline__ unsigned nib_hi_x16(unsigned A, unsigned mask_f0)   // (A >> 8*BYTE) & 0xf0
+{
+  unsigned d;
+  if (BYTE == 0) asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(d) : "s"(mask_f0), "v"(A));
+  else if (BYTE == 1) asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(d) : "s"(mask_f0), "v"(A));
+  else if (BYTE == 2) asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(d) : "s"(mask_f0), "v"(A));
+  else asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(d) : "s"(mask_f0), "v"(A));
+  return d;
+}
+
+template <int BYTE>
+__device__ __forceinline__ int add_sext_byte(int x, int packed)   // x + (int)(signed char)(packed >> 8*BYTE)
+{
+  int d;
+  if (BYTE == 0) asm("v_add_u32_sdwa %0, %1, sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(d) : "v"(x), "v"(packed));
+  else if (BYTE == 1) asm("v_add_u32_sdwa %0, %1, sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(d) : "v"(x), "v"(packed));
+  else if (BYTE == 2) asm("v_add_u32_sdwa %0, %1, sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(d) : "v"(x), "v"(packed));
+  else asm("v_add_u32_sdwa %0, %1, sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(d) : "v"(x), "v"(packed));
+  return d;
+}
+
+// candidate bytes: once per launch.
+template <int BLOCK>
+__device__ __forceinline__ void fast_tabs_init(FastTabs &ft, const int (&tab)[RAMX_NCLASS][4])
+{
+  if (threadIdx.x < 16)
+  {
+    const int cls = threadIdx.x;
+    unsigned pk = 0;
+    if (cls < RAMX_NCLASS)
+      pk = ((unsigned)tab[cls][0] & 0xffu) | (((unsigned)tab[cls][1] & 0xffu) << 8) | (((unsigned)tab[cls][2] & 0xffu) << 16) |
+           (((unsigned)tab[cls][3] & 0xffu) << 24);
+    ft.row[cls][0] = (int)pk; ft.row[cls][1] = 0; ft.row[cls][2] = 0; ft.row[cls][3] = 0;
+  }
+}
+// winner dword of the column whose winner is `besta` (threads 0..15 of the caller's group)
+__device__ __forceinline__ void fast_tabs_winner(FastTabs &ft, const int *tab_besta /* old-format table of besta */, int i)
+{
+  if (i < 16) ft.row[i][1] = i < RAMX_NCLASS ? tab_besta[i * TAB_STRIDE + 4] : 0;
+}
+
+// In-bounds, chain-free band of the register-resident kernels (the steady state of a run): per cell
+//   sub = Pm + sF;  m = max3(sub, eC, Pe);  e = max3(sub + go, eC, Pe) + ge          (5 VALU, chain of 2)
+// The four candidates take two cells per v_max3; their shared deletion term max_k e_k is folded in at the end.
+// The best cell of the row (value, lowest index on ties: bnw_extend.c:1020-1024) is tracked as a packed key
+// (m << 4) | (15 - (j & 15)) per 16-cell group, two cells per v_max3; exact while |m| < 2^27 (checked on the host).
+template <int W, int BLOCK>
+__device__ __forceinline__ void prk_band_fast(const int go, const int ge, const FastTabs &ft, short *sD, const int r,
+                                              const unsigned (&w)[(2 * W + 1 + 8) / 8 + 2], int (&M)[2 * W + 1], LaneDP &D)
+{
+  constexpr int B = 2 * W + 1, NG = (B + 15) / 16;
+  const int ph4 = 4 * ((r + 8) & 7);
+  const unsigned mask_f0 = 0xf0u;
+  short *myD = sD + 2 * threadIdx.x;
+  const char *tb = reinterpret_cast<const char *>(&ft.row[0][0]);
+  int eC = NEG, mPrev = NEG, maxE = NEG, ePend = NEG, kPend = NEG;
+  int bA[4] = { NEG, NEG, NEG, NEG }, pend[4] = { NEG, NEG, NEG, NEG };
+  int kg[NG];
+#pragma unroll
+  for (int g = 0; g < NG; g++) kg[g] = -2147483647 - 1;
+  // compile-time cell index: the band is generated step by step (no reliance on the loop unroller, whose size limit
+  // would otherwise leave the row in scratch memory).  Table rows and the previous row's e are fetched PD steps ahead
+  // of their use (a lone wave per SIMD -- one family per workgroup -- has nobody to hide the LDS latency behind).
+  constexpr int PD = PRK_FETCH_AHEAD;
+  unsigned A = 0, Alo = 0;
+  int2 rowQ[PD];                                    // {candidate bytes, M[besta][base]} of steps j .. j+PD-1
+  int dQ[PD];                                       // e - m of the previous row's cells j+1 .. j+PD
+  auto fetch_row = [&](auto jc) __attribute__((always_inline))
+  {
+    constexpr int jn = decltype(jc)::value;         // the step whose base is looked up
+    if constexpr ((jn & 7) == 0 || jn == 0)
+    {
+      A = __builtin_amdgcn_alignbit(w[(jn >> 3) + 1], w[jn >> 3], ph4);
+      Alo = A & 0x0f0f0f0fu;                        // low nibbles only: (byte << 4) is then the row offset of the class
+    }
+    constexpr int byte = (jn & 7) / 2;
+    unsigned off;
+    if constexpr ((jn & 1) == 0) off = nib_lo_x16<byte>(Alo);
+    else off = nib_hi_x16<byte>(A, mask_f0);
+    return *reinterpret_cast<const int2 *>(tb + off);
+  };
+  static_for([&](auto kc) __attribute__((always_inline))
+  {
+    constexpr int k = decltype(kc)::value;
+    if constexpr (k <= B) rowQ[k] = fetch_row(std::integral_constant<int, (k <= B ? k : 0)>{});
+    else rowQ[k] = make_int2(0, 0);
+    dQ[k] = (k + 1 < B) ? (int)myD[((k + 1) >> 1) * (2 * BLOCK) + ((k + 1) & 1)] : 0;
+  }, std::make_integer_sequence<int, PD>{});
+  auto step = [&](auto jc) __attribute__((always_inline))
+  {
+    constexpr int j = decltype(jc)::value;
+    if constexpr ((j & (PRK_FAST_GROUP - 1)) == 0)
+    {
+      // pin the accumulators to their group: nothing but data dependences orders pure arithmetic against
+      // sched_barrier during instruction selection, and a sunk accumulation keeps every table row alive
+      asm volatile("" ::"v"(bA[0]), "v"(bA[1]), "v"(bA[2]), "v"(bA[3]), "v"(maxE), "v"(kg[(j > 0 ? j - 1 : 0) >> 4]));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    const int sv = rowQ[0].x, sF = rowQ[0].y;
+    const int dCur = dQ[0];
+#pragma unroll
+    for (int k = 0; k + 1 < PD; k++) { rowQ[k] = rowQ[k + 1]; dQ[k] = dQ[k + 1]; }
+    if constexpr (j + PD <= B) rowQ[PD - 1] = fetch_row(std::integral_constant<int, (j + PD <= B ? j + PD : 0)>{});
+    if constexpr (j + PD + 1 < B) dQ[PD - 1] = (int)myD[((j + PD + 1) >> 1) * (2 * BLOCK) + ((j + PD + 1) & 1)];
+    // candidates' cell j-1 of row r+1: substitution from m_{j-1} of row r (the base of that cell is this step's)
+    if constexpr (j >= 1)
+    {
+      const int t4[4] = { add_sext_byte<0>(mPrev, sv), add_sext_byte<1>(mPrev, sv), add_sext_byte<2>(mPrev, sv), add_sext_byte<3>(mPrev, sv) };
+      if constexpr ((j & 1) != 0)
+      {
+#pragma unroll
+        for (int c = 0; c < 4; c++) pend[c] = t4[c];
+      }
+      else
+      {
+#pragma unroll
+        for (int c = 0; c < 4; c++) bA[c] = imax3(bA[c], pend[c], t4[c]);
+      }
+    }
+    if constexpr (j < B)
+    {
+      const int Pm = M[j];
+      int Pe = NEG;
+      if constexpr (j + 1 < B) Pe = M[j + 1] + dCur;
+      const int sub = Pm + sF;                       // bnw_extend.c:950-956
+      const int m = vmax3(sub, eC, Pe);              // max(sub, max(ins, del)), :1007-1018
+      const int e = vmax3(sub + go, eC, Pe) + ge;
+      M[j] = m;
+      myD[(j >> 1) * (2 * BLOCK) + (j & 1)] = (short)(e - m);
+      const int key = (int)(((unsigned)m << 4) | (unsigned)(15 - (j & 15)));
+      if constexpr ((j & 1) == 0 && j + 1 < B) kPend = key;
+      else if constexpr ((j & 1) != 0) kg[j >> 4] = imax3(kg[j >> 4], kPend, key);
+      else kg[j >> 4] = imax(kg[j >> 4], key);
+      // deletion term of candidate cell j-1 is e_j (cells 1..B-1)
+      if constexpr (j >= 1)
+      {
+        if constexpr ((j & 1) != 0) ePend = e;
+        else maxE = imax3(maxE, ePend, e);
+      }
+      mPrev = m;
+      eC = e;
+    }
+  };
+  static_for(step, std::make_integer_sequence<int, B + 1>{});
+  // B is odd: the last candidate term (step B) is still pending; B-1 is even: every e has been folded
+#pragma unroll
+  for (int c = 0; c < 4; c++) D.bestA[c] = imax3(bA[c], (B & 1) ? pend[c] : NEG, maxE);
+  // best cell: highest value, lowest group on ties (inside a group the key already prefers the lowest cell)
+  int bestv = kg[NG - 1] >> 4, bkey = kg[NG - 1], bg = NG - 1;
+#pragma unroll
+  for (int g = NG - 2; g >= 0; g--)
+  {
+    const int v = kg[g] >> 4;
+    const bool take = v >= bestv;
+    bestv = take ? v : bestv;
+    bkey = take ? kg[g] : bkey;
+    bg = take ? g : bg;
+  }
+  D.bestF = bestv;
+  D.jbest = 16 * bg + 15 - (bkey & 15);
+}
+
+template <int W, bool OOB, int BLOCK, bool INIT = false>
+__device__ __forceinline__ void prk_band(const int go, const int ge, const int *s_tab, const FastTabs &ft, short *sD, const int r,
+                                         const unsigned (&w)[(2 * W + 1 + 8) / 8 + 2], const int jlo, const int jhi,
+                                         int (&M)[2 * W + 1], LaneDP &D)
+{
+  constexpr int B = 2 * W + 1;
+  if (!OOB && !INIT)
+  {
+    prk_band_fast<W, BLOCK>(go, ge, ft, sD, r, w, M, D);
+    return;
+  }
+  const int edgeF = (r < W) ? go + (r + 1) * ge : SENT;
+  const int edgeC = (r + 1 < W) ? go + (r + 2) * ge : SENT;
+  const int ph4 = 4 * ((r + 8) & 7);
+  short *myD = sD + 2 * threadIdx.x;
+#pragma unroll
+  for (int j = 0; j <= B; j++)
+  {
+    // the row itself occupies B registers: keep the scheduler from hoisting every table lookup of the fully
+    // unrolled band to the top.  This is the rarely taken masked path: small groups, lowest register pressure
+    if ((j & (PRK_OOB_GROUP - 1)) == 0) __builtin_amdgcn_sched_barrier(0);
+    const unsigned A = __builtin_amdgcn_alignbit(w[(j >> 3) + 1], w[j >> 3], ph4);
+    const unsigned bc = (A >> (4 * (j & 7))) & 15u;
+    StepU u;
+    u.j = j; u.first = (j == 0); u.hi = 2147483647;
+    u.vF = (j < W) ? edgeF : SENT;
+    u.vC = u.first ? NEG : ((j - 1 < W) ? edgeC : SENT);
+    const StepT t = fetch_step<OOB>(s_tab, bc, (j >= jlo) && (j <= jhi), j == 0);
+    if (j < B)
+    {
+      const int Pm = M[j];
+      int PeNext = NEG;
+      if (j + 1 < B) PeNext = M[j + 1] + (int)myD[((j + 1) >> 1) * (2 * BLOCK) + ((j + 1) & 1)];   // previous row's e of cell j+1
+      int m, e;
+      band_step<INIT, true, OOB, false>(go, ge, W, u, t, Pm, PeNext, D, m, e);
+      M[j] = m;
+      myD[(j >> 1) * (2 * BLOCK) + (j & 1)] = (short)(e - m);
+    }
+    else
+    {
+      int dm, de;
+      band_step<INIT, false, OOB, false>(go, ge, W, u, t, 0, 0, D, dm, de);
+    }
+  }
+}
+
+template <int W, int BLOCK>
+__global__ __launch_bounds__(BLOCK, 2) void ramx_persistent_kernel(const PArgs a)
+{
+  constexpr int B = 2 * W + 1, Q = W + 1, NW = (B + 8) / 8 + 2, WPB = BLOCK / 64, RS = 2 * BLOCK;   // RS: shorts per cell-pair row of sD
+  // one object, tables first: their LDS addresses must fit the 16-bit offset field of the ds_read that uses them
+  struct Smem
+  {
+    FastTabs ft;
+    int tab4[4][TAB_ROWS * TAB_STRIDE];                // one score table per winner base (masked path)
+    long long red[WPB][4];
+    long long vote[4];
+    int fail, pad[3];
+    short d[((B + 1) / 2) * RS];                       // d = e - m, [cell pair][thread][parity]
+  };
+  __shared__ __attribute__((aligned(16))) Smem sm;
+  FastTabs &s_ft = sm.ft;
+  int (&s_tab4)[4][TAB_ROWS * TAB_STRIDE] = sm.tab4;
+  long long (&s_red)[WPB][4] = sm.red;
+  long long (&s_vote)[4] = sm.vote;
+  int &s_fail = sm.fail;
+  short *sD = sm.d;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tile = blockIdx.x * WPB + wave;
+  const bool live = tile < (a.Np >> 6);
+  const int n = (live ? tile : 0) * 64 + lane;
+  int4 *S = a.S + (size_t)(live ? tile : 0) * Q * 64 + lane;
+  short *myD = sD + 2 * threadIdx.x;
+
+  // ---- row state -> registers (m) and LDS (e - m) -----------------------------------------
+  int M[B];
+  int high, pos, thigh = 0, tpos = 0;
+  {
+#pragma unroll
+    for (int q = 0; q < W; q++)
+    {
+      const int4 v = S[(size_t)q * 64];
+      M[2 * q] = v.x; M[2 * q + 1] = v.z;
+      myD[q * RS] = (short)(v.y - v.x); myD[q * RS + 1] = (short)(v.w - v.z);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const int4 v = S[(size_t)W * 64];
+    M[B - 1] = v.x; myD[W * RS] = (short)(v.y - v.x); high = v.z; pos = v.w;
+  }
+  const int2 bd = a.bounds[n];
+  const int shard = blockIdx.x % NSHARD;
+  const int my_shard_blocks = (a.nblocks - (lane & (NSHARD - 1)) + NSHARD - 1) / NSHARD;   // wave 0: blocks arriving on shard `lane & 31`
+
+  long long max_ext = 0;
+  int max_row = -1, rows_done = 0, ovf = 0, stopped = 0, failed = 0;
+  if (threadIdx.x == 0) s_fail = 0;
+  for (int i = threadIdx.x; i < 4 * TAB_ROWS * TAB_STRIDE; i += BLOCK)
+  {
+    const int bt = i / (TAB_ROWS * TAB_STRIDE), e = i % (TAB_ROWS * TAB_STRIDE), row = e / TAB_STRIDE, col = e % TAB_STRIDE;
+    int v = 0;
+    if (row < RAMX_NCLASS) v = (col < 4) ? a.tab[row][col] : (col == 4 ? a.tab[row][bt] : 0);
+    s_tab4[bt][e] = v;
+  }
+  fast_tabs_init<BLOCK>(s_ft, a.tab);
+  __syncthreads();
+
+#ifdef RAMX_PRK_TIMING
+  unsigned long long tsum[6] = { 0, 0, 0, 0, 0, 0 }, tlast = wall_clock64();
+#endif
+  for (int r = 0; r < a.L; r++)
+  {
+    PRK_TICK(5);
+    // ---- base words of this column (independent of the vote: issued before the wait) -------
+    unsigned w[NW];
+    {
+      const unsigned *bp = a.bases + (size_t)((r + 8) >> 3) * a.Np + n;
+#pragma unroll
+      for (int k = 0; k < NW; k++) w[k] = bp[(size_t)k * a.Np];
+    }
+    // ---- vote of row r -----------------------------------------------------------------------
+    if (wave == 0)
+    {
+      long long v[4] = { 0, 0, 0, 0 };
+      if (r == 0)
+      {
+        if (lane < NSHARD) { const long long *p = a.sums0 + lane * 4; v[0] = p[0]; v[1] = p[1]; v[2] = p[2]; v[3] = p[3]; }
+      }
+      else
+      {
+        // lane = shard + 32 * half polls words 2*half, 2*half+1 of "its" shard: one 16-byte load per lane and round
+        // (a quarter of the requests of four 8-byte loads on 32 lanes; the poll competes with the adds it waits for)
+        const int sidx = lane & (NSHARD - 1), half = lane >> 5;
+        const unsigned long long *src = &a.vote[(size_t)(r % 3) * NSHARD + sidx].word[2 * half];
+        unsigned spins = 0;
+        bool done = my_shard_blocks <= 0 || (a.nranks > 1 && blockIdx.x != 0);   // multi-rank: only the exchanger needs the local total
+        unsigned long long x0 = 0, x1 = 0;
+        for (;;)
+        {
+          if (!done)
+          {
+            typedef unsigned v4u __attribute__((ext_vector_type(4)));
+            v4u q;
+            asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(q) : "v"(src) : "memory");
+            x0 = ((unsigned long long)q.y << 32) | q.x;
+            x1 = ((unsigned long long)q.w << 32) | q.z;
+            done = (x0 >> 54) >= (unsigned long long)my_shard_blocks && (x1 >> 54) >= (unsigned long long)my_shard_blocks;
+          }
+          if (__all(done)) break;
+          if (++spins > PRK_SPIN_LIMIT || ((spins & 1023u) == 0 && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0))
+          {
+            failed = 1;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+        long long y0 = 0, y1 = 0;
+        if (my_shard_blocks > 0 && !failed && !(a.nranks > 1 && blockIdx.x != 0))
+        {
+          y0 = (long long)(x0 & (PRK_TICKET - 1)) - (long long)(x0 >> 54) * (long long)PRK_BIAS;
+          y1 = (long long)(x1 & (PRK_TICKET - 1)) - (long long)(x1 >> 54) * (long long)PRK_BIAS;
+        }
+        // fold the 32 shards inside each half-wave; lanes 0 / 32 end up with words {0,1} / {2,3}
+#pragma unroll
+        for (int m = 16; m >= 1; m >>= 1) { y0 += __shfl_xor(y0, m, 64); y1 += __shfl_xor(y1, m, 64); }
+        v[0] = __shfl(y0, 0, 64); v[1] = __shfl(y1, 0, 64); v[2] = __shfl(y0, 32, 64); v[3] = __shfl(y1, 32, 64);
+      }
+      if (r == 0)
+      {
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = wave_sum_ll(v[k]);
+      }
+      if (a.nranks > 1 && r > 0 && !failed)
+      {
+        // ---- cross-device step: v[] is this rank's total (identical in all lanes) -----------
+        const unsigned long long tag = (unsigned long long)(r & 0xffff) << 48;
+        if (blockIdx.x == 0 && lane < a.nranks)
+        {
+          PeerBox *pb = a.peers[lane];
+#pragma unroll
+          for (int k = 0; k < 4; k++)
+          {
+            if (v[k] >= PEER_VBIAS || v[k] <= -PEER_VBIAS) failed = 1;     // cannot be encoded: fail loudly
+            __hip_atomic_store(&pb->slot[r % 3][a.rank][k], tag | ((unsigned long long)(v[k] + PEER_VBIAS) & PEER_VMASK),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          }
+        }
+        unsigned long long y[4] = { 0, 0, 0, 0 };
+        bool got = lane >= a.nranks;
+        unsigned spins = 0;
+        for (;;)
+        {
+          if (!got)
+          {
+#pragma unroll
+            for (int k = 0; k < 4; k++) y[k] = __hip_atomic_load(&a.box->slot[r % 3][lane][k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            got = (y[0] >> 48) == (tag >> 48) && (y[1] >> 48) == (tag >> 48) && (y[2] >> 48) == (tag >> 48) && (y[3] >> 48) == (tag >> 48);
+          }
+          if (__all(got)) break;
+          if (++spins > PRK_SPIN_LIMIT || ((spins & 1023u) == 0 && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0))
+          {
+            failed = 1;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+        failed = __any(failed) ? 1 : 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+          v[k] = wave_sum_ll((lane < a.nranks && !failed) ? (long long)(y[k] & PEER_VMASK) - PEER_VBIAS : 0LL);
+      }
+      {
+        // the winner's substitution column of the fast-path tables (same argmax rule as below, ram_extend.c:1064-1086)
+        long long cw = 0;
+        int bw = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+          if (v[k] > cw) { cw = v[k]; bw = k; }
+        fast_tabs_winner(s_ft, s_tab4[bw], lane);
+      }
+      if (lane == 0)
+      {
+        s_vote[0] = v[0]; s_vote[1] = v[1]; s_vote[2] = v[2]; s_vote[3] = v[3];
+        s_fail = failed;
+        if (failed) __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    PRK_TICK(0);                 // wave 0: vote seen (other waves: nothing)
+    __syncthreads();
+    PRK_TICK(1);                 // released by the block barrier
+    if (__builtin_amdgcn_readfirstlane(s_fail)) { failed = 1; break; }
+    long long curr = 0;
+    int besta = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+    {
+      // the vote is wave-uniform: move it to scalar registers so that the whole stop rule runs on the SALU and
+      // none of its state (max_ext, max_row, ...) occupies vector registers next to the row
+      const long long vv = s_vote[k];
+      const long long vk = ((long long)__builtin_amdgcn_readfirstlane((int)(vv >> 32)) << 32) |
+                           (long long)(unsigned)__builtin_amdgcn_readfirstlane((int)vv);
+      if (vk > 2147483647LL || vk < -2147483648LL) ovf = 1;
+      if (vk > curr) { curr = vk; besta = k; }
+    }
+    int dist = max_row - r;
+    dist = dist < 0 ? -dist : dist;
+    const bool new_max = curr >= max_ext + (long long)dist * a.minimp;
+    if (new_max) { max_row = r; max_ext = curr; }
+    int d2 = r - max_row;
+    d2 = d2 < 0 ? -d2 : d2;
+    stopped = d2 >= a.when_to_stop;
+    rows_done = r + 1;
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.cons_out[r] = (signed char)besta;
+    // block 0 clears the vote set of row r+2 (see the protocol above)
+    if (blockIdx.x == 0 && threadIdx.x < NSHARD)
+    {
+      PShard *z = a.vote + (size_t)((r + 2) % 3) * NSHARD + threadIdx.x;
+#pragma unroll
+      for (int k = 0; k < 4; k++) __hip_atomic_store(&z->word[k], 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const int *s_tab = s_tab4[besta];                // column 4 of table `besta` holds M[besta][class]
+
+    // ---- the band, rows in registers ---------------------------------------------------------
+    int contrib[4] = { 0, 0, 0, 0 };       // each in [0, 2^31): clamped at 0 below, capped from below by high + cap
+    if (live)
+    {
+      const int jlo = bd.x - r, jhi = bd.y - r;
+      LaneDP D;
+      D.eC = NEG; D.mPrev = NEG - 1000000; D.bestF = NEG; D.jbest = 0;
+#pragma unroll
+      for (int c = 0; c < 4; c++) { D.eA[c] = NEG; D.bestA[c] = NEG; }
+      const bool all_in = a.pack_ok && __all((jlo <= 0) && (jhi >= B));
+      if (all_in) prk_band<W, false, BLOCK>(a.go, a.ge, s_tab, s_ft, sD, r, w, jlo, jhi, M, D);
+      else prk_band<W, true, BLOCK>(a.go, a.ge, s_tab, s_ft, sD, r, w, jlo, jhi, M, D);
+      if (D.bestF > high) { high = D.bestF; pos = r + D.jbest - W; }   // ram_extend.c:1140-1150
+      if (new_max) { thigh = high; tpos = pos; }                        // :1203-1207
+      if (n < a.Nx)
+      {
+        const int capv = high + a.cap;
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+        {
+          const int b = D.bestA[c] < 0 ? 0 : D.bestA[c];
+          contrib[c] = (b >= capv) ? b : capv;
+        }
+      }
+    }
+    PRK_TICK(2);                 // band done
+    if (stopped || r == a.L - 1) break;     // the vote of row r+1 will not be consumed
+    {
+      long long tot[4];
+#pragma unroll
+      for (int c = 0; c < 4; c++) tot[c] = wave_sum_nonneg31(contrib[c]);
+      if (lane == 0)
+      {
+#pragma unroll
+        for (int c = 0; c < 4; c++) s_red[wave][c] = tot[c];
+      }
+    }
+    __syncthreads();
+    PRK_TICK(3);                 // wave reduction + block barrier
+    if (blockIdx.x == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // block 0: its zeroing stores first
+    if (threadIdx.x < 4)
+    {
+      long long t = 0;
+#pragma unroll
+      for (int wv = 0; wv < WPB; wv++) t += s_red[wv][threadIdx.x];
+      PShard *sh = a.vote + (size_t)((r + 1) % 3) * NSHARD + shard;
+      __hip_atomic_fetch_add(&sh->word[threadIdx.x], (unsigned long long)t + PRK_BIAS + PRK_TICKET, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+    }
+    PRK_TICK(4);                 // contribution issued
+  }
+#ifdef RAMX_PRK_TIMING
+  if (a.dbg != NULL && (threadIdx.x & 63) == 0)
+  {
+#pragma unroll
+    for (int k = 0; k < 6; k++) a.dbg[((size_t)blockIdx.x * WPB + wave) * 8 + k] = tsum[k];
+  }
+#endif
+
+  // ---- write back: rows (so that the device state can be inspected / resumed), trim, control ----
+  if (live)
+  {
+#pragma unroll
+    for (int q = 0; q < W; q++)
+    {
+      S[(size_t)q * 64] = make_int4(M[2 * q], M[2 * q] + (int)myD[q * RS], M[2 * q + 1], M[2 * q + 1] + (int)myD[q * RS + 1]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    S[(size_t)W * 64] = make_int4(M[B - 1], M[B - 1] + (int)myD[W * RS], high, pos);
+    a.trim[n] = make_int2(thigh, tpos);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+  {
+    RamxCtl o;
+    o.max_ext = max_ext; o.max_row = max_row; o.stopped = stopped; o.rows_done = rows_done; o.overflow = ovf; o.besta = 0;
+    o.pad = failed;
+    *a.ctl_out = o;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// batch mode: one BLOCK = one family
+// ------------------------------------------------------------------------------------------
+//
+// Real inputs are hundreds of families of ~100 flanks each (util/extend-stk.pl runs one RAMExtend process per
+// family).  A family of up to BLOCK flanks fits one workgroup, so its per-column vote is a block-local LDS
+// reduction: no device-wide barrier, no atomics, no cooperative launch, any number of families per launch (blocks
+// that are not resident simply wait their turn), each family stopping on its own fit-preferred rule.  Rows live in
+// registers / LDS exactly as in the persistent kernel; the boundary row and the candidates of row 0 are produced
+// in-kernel (column "-1").
+
+
+struct FArgs
+{
+  const unsigned *bases;
+  const int2 *bounds;
+  const FamDesc *fam;
+  int2 *trim;                   // per flank
+  RamxCtl *ctl_out;             // per family
+  signed char *cons_out;        // [family][L]
+  int Np, L, go, ge, cap, minimp, when_to_stop;
+  int tab[RAMX_NCLASS][4];
+  int pack_ok;
+};
+
+template <int W, int BLOCK>
+__global__ __launch_bounds__(BLOCK, 2) void ramx_family_kernel(const FArgs a)
+{
+  constexpr int B = 2 * W + 1, NW = (B + 8) / 8 + 2, WPB = BLOCK / 64, RS = 2 * BLOCK;
+  struct Smem     // tables first (16-bit ds offsets), see the persistent kernel
+  {
+    FastTabs ft;
+    int tab4[4][TAB_ROWS * TAB_STRIDE];
+    long long red[2][WPB][4];
+    short d[((B + 1) / 2) * RS];
+  };
+  __shared__ __attribute__((aligned(16))) Smem sm;
+  FastTabs &s_ft = sm.ft;
+  int (&s_tab4)[4][TAB_ROWS * TAB_STRIDE] = sm.tab4;
+  long long (&s_red)[2][WPB][4] = sm.red;
+  short *sD = sm.d;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const FamDesc fd = a.fam[blockIdx.x];
+  const int vwave = wave;
+  const bool live = vwave < fd.ntiles;
+  const int n = (fd.tile0 + (live ? vwave : 0)) * 64 + lane;
+  const bool active = live && (vwave * 64 + lane) < fd.nx;
+
+  for (int i = threadIdx.x; i < 4 * TAB_ROWS * TAB_STRIDE; i += BLOCK)
+  {
+    const int bt = i / (TAB_ROWS * TAB_STRIDE), e = i % (TAB_ROWS * TAB_STRIDE), row = e / TAB_STRIDE, col = e % TAB_STRIDE;
+    int v = 0;
+    if (row < RAMX_NCLASS) v = (col < 4) ? a.tab[row][col] : (col == 4 ? a.tab[row][bt] : 0);
+    s_tab4[bt][e] = v;
+  }
+  fast_tabs_init<BLOCK>(s_ft, a.tab);
+  __syncthreads();
+
+  int M[B];
+#pragma unroll
+  for (int j = 0; j < B; j++) M[j] = 0;
+  int high = 0, pos = 0, thigh = 0, tpos = 0;
+  const int2 bd = a.bounds[n];
+  long long max_ext = 0;
+  int max_row = -1, rows_done = 0, ovf = 0, stopped = 0;
+
+  // base words of the lane's window: the window moves by one nibble per column, so the words are carried across
+  // columns and ONE new word is loaded every eighth column (its first use is at the far end of the band)
+  unsigned w[NW];
+  {
+    const unsigned *bp = a.bases + n;               // column -1 starts at word (r + 8) >> 3 = 0
+#pragma unroll
+    for (int k = 0; k < NW; k++) w[k] = bp[(size_t)k * a.Np];
+  }
+  for (int r = -1; r < a.L; r++)
+  {
+    if (r >= 0 && ((r + 8) & 7) == 0)
+    {
+#pragma unroll
+      for (int k = 0; k + 1 < NW; k++) w[k] = w[k + 1];
+      w[NW - 1] = a.bases[(size_t)(((r + 8) >> 3) + NW - 1) * a.Np + n];
+    }
+    int besta = 0;
+    bool new_max = false;
+    if (r >= 0)
+    {
+      // vote of row r: block-local (written at the end of the previous iteration, double buffered)
+      long long curr = 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+      {
+        long long vv = 0;
+#pragma unroll
+        for (int wv = 0; wv < WPB; wv++) vv += s_red[r & 1][wv][k];
+        // wave-uniform: keep the vote and the stop rule on the scalar unit (see the persistent kernel)
+        const long long vk = ((long long)__builtin_amdgcn_readfirstlane((int)(vv >> 32)) << 32) |
+                             (long long)(unsigned)__builtin_amdgcn_readfirstlane((int)vv);
+        if (vk > 2147483647LL || vk < -2147483648LL) ovf = 1;
+        if (vk > curr) { curr = vk; besta = k; }
+      }
+      int dist = max_row - r;
+      dist = dist < 0 ? -dist : dist;
+      new_max = curr >= max_ext + (long long)dist * a.minimp;
+      if (new_max) { max_row = r; max_ext = curr; }
+      int d2 = r - max_row;
+      d2 = d2 < 0 ? -d2 : d2;
+      stopped = d2 >= a.when_to_stop;
+      rows_done = r + 1;
+      if (threadIdx.x == 0) a.cons_out[(size_t)fd.id * a.L + r] = (signed char)besta;
+    }
+    const int *s_tab = s_tab4[besta];
+    if (r >= 0 && a.pack_ok)
+    {
+      // winner rows of the fast-path tables; everybody has left the previous column's band (barrier at its end)
+      fast_tabs_winner(s_ft, s_tab, threadIdx.x);
+      __syncthreads();
+    }
+    int contrib[4] = { 0, 0, 0, 0 };
+    if (live)
+    {
+      const int jlo = bd.x - r, jhi = bd.y - r;
+      LaneDP D;
+      D.eC = NEG; D.mPrev = NEG - 1000000; D.bestF = NEG; D.jbest = 0;
+#pragma unroll
+      for (int c = 0; c < 4; c++) { D.eA[c] = NEG; D.bestA[c] = NEG; }
+      if (r < 0)
+        prk_band<W, true, BLOCK, true>(a.go, a.ge, s_tab, s_ft, sD, r, w, jlo, jhi, M, D);
+      else
+      {
+        const bool all_in = a.pack_ok && __all((jlo <= 0) && (jhi >= B));
+        if (all_in) prk_band<W, false, BLOCK>(a.go, a.ge, s_tab, s_ft, sD, r, w, jlo, jhi, M, D);
+        else prk_band<W, true, BLOCK>(a.go, a.ge, s_tab, s_ft, sD, r, w, jlo, jhi, M, D);
+        if (D.bestF > high) { high = D.bestF; pos = r + D.jbest - W; }
+        if (new_max) { thigh = high; tpos = pos; }
+      }
+      if (active)
+      {
+        const int capv = high + a.cap;
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+        {
+          const int b = D.bestA[c] < 0 ? 0 : D.bestA[c];
+          contrib[c] = (b >= capv) ? b : capv;
+        }
+      }
+    }
+    if (stopped || r == a.L - 1) break;
+    {
+      long long tot[4];
+#pragma unroll
+      for (int c = 0; c < 4; c++) tot[c] = wave_sum_nonneg31(contrib[c]);
+      if (lane == 0)
+      {
+#pragma unroll
+        for (int c = 0; c < 4; c++) s_red[(r + 1) & 1][wave][c] = tot[c];
+      }
+    }
+    __syncthreads();
+  }
+  if (live) a.trim[n] = make_int2(thigh, tpos);
+  if (threadIdx.x == 0)
+  {
+    RamxCtl o;
+    o.max_ext = max_ext; o.max_row = max_row; o.stopped = stopped; o.rows_done = rows_done; o.overflow = ovf; o.besta = 0; o.pad = 0;
+    a.ctl_out[fd.id] = o;
+  }
+}
+
