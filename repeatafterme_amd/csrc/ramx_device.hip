@@ -800,8 +800,10 @@ extern "C" int ramx_dev_run_direction(ramx_dev *d, ramx_run_info *info)
     if (frc != RAMX_OK) return frc;
     if (bad)
     {
-      fprintf(stderr, "ramx: cross-device persistent launch gave up on some rank; repeating the direction with per-column launches\n");
+      fprintf(stderr, "ramx: cross-device persistent launch gave up on some rank; repeating the direction with per-column launches "
+                      "and leaving the mailbox path off for the rest of this process\n");
       persistent = false;
+      d->peer_ready = 0;          // agreed by all ranks (the flag above is reduced): nobody tries the mailboxes again
       HIPCHK(hipMemsetAsync(d->d_sums, 0, 3 * NSHARD * 4 * sizeof(long long), d->stream));
       a.r = -1; a.S_in = d->d_state[0]; a.S_out = d->d_state[1]; a.ctl_in = d->d_ctl; a.ctl_out = d->d_ctl + 1;
       a.sums_in = slot(0); a.sums_out = slot(0); a.sums_zero = slot(1); a.nshards_in = NSHARD;
