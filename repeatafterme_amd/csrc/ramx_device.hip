@@ -486,7 +486,13 @@ static int prk_plan(int tiles, int *block, int *blocks)
   int cap = 0, rc;
   *block = 0; *blocks = 0;
   if ((rc = prk_capacity_blocks<W, 256>(&cap)) != RAMX_OK) return rc;
-  if ((tiles + 3) / 4 <= cap) { *block = 256; *blocks = (tiles + 3) / 4; return RAMX_OK; }
+  if ((tiles + 3) / 4 <= cap)
+  {
+    *block = 256; *blocks = (tiles + 3) / 4;
+    const char *mb = getenv("RAMX_PRK_MIN_BLOCKS");      // experiment: pad the grid with workgroups that own no tile
+    if (mb && atoi(mb) > *blocks && atoi(mb) <= cap) *blocks = atoi(mb);
+    return RAMX_OK;
+  }
   if ((rc = prk_capacity_blocks<W, 512>(&cap)) != RAMX_OK) return rc;
   if ((tiles + 7) / 8 <= cap) { *block = 512; *blocks = (tiles + 7) / 8; }
   return RAMX_OK;

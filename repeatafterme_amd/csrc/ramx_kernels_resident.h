@@ -61,7 +61,7 @@ struct PArgs
   unsigned long long *dbg;      // -DRAMX_PRK_TIMING builds only: [block][8] phase sums in 10 ns ticks
 };
 
-#define PRK_SPIN_LIMIT (1u << 22)
+#define PRK_SPIN_LIMIT (1u << 21)
 #ifdef RAMX_PRK_TIMING
 #define PRK_TICK(k) do { const unsigned long long t_ = wall_clock64(); tsum[k] += t_ - tlast; tlast = t_; } while (0)
 #else
@@ -550,7 +550,9 @@ __global__ __launch_bounds__(BLOCK, 2) void ramx_persistent_kernel(const PArgs a
       D.eC = NEG; D.mPrev = NEG - 1000000; D.bestF = NEG; D.jbest = 0;
 #pragma unroll
       for (int c = 0; c < 4; c++) { D.eA[c] = NEG; D.bestA[c] = NEG; }
-      const bool all_in = a.pack_ok && __all((jlo <= 0) && (jhi >= B));
+      // padding lanes (no flank: their base stream is all N, their vote is masked) must not force the whole wave onto
+      // the masked path -- with N not a multiple of 64 that one slow wave would gate every column
+      const bool all_in = a.pack_ok && __all((n >= a.Nx) || ((jlo <= 0) && (jhi >= B)));
       if (all_in) prk_band<W, false, BLOCK>(a.go, a.ge, s_tab, s_ft, sD, r, w, jlo, jhi, M, D);
       else prk_band<W, true, BLOCK>(a.go, a.ge, s_tab, s_ft, sD, r, w, jlo, jhi, M, D);
       if (D.bestF > high) { high = D.bestF; pos = r + D.jbest - W; }   // ram_extend.c:1140-1150
@@ -750,7 +752,9 @@ __global__ __launch_bounds__(BLOCK, 2) void ramx_family_kernel(const FArgs a)
         prk_band<W, true, BLOCK, true>(a.go, a.ge, s_tab, s_ft, sD, r, w, jlo, jhi, M, D);
       else
       {
-        const bool all_in = a.pack_ok && __all((jlo <= 0) && (jhi >= B));
+        // padding lanes (no flank: their base stream is all N, their vote is masked) must not force the whole wave onto
+        // the masked path -- with N not a multiple of 64 that one slow wave would gate every column
+        const bool all_in = a.pack_ok && __all((!active) || ((jlo <= 0) && (jhi >= B)));
         if (all_in) prk_band<W, false, BLOCK>(a.go, a.ge, s_tab, s_ft, sD, r, w, jlo, jhi, M, D);
         else prk_band<W, true, BLOCK>(a.go, a.ge, s_tab, s_ft, sD, r, w, jlo, jhi, M, D);
         if (D.bestF > high) { high = D.bestF; pos = r + D.jbest - W; }

@@ -107,7 +107,7 @@ __global__ __launch_bounds__(BLOCK) void ramx_column_kernel(const KArgs a)
     for (int c = 0; c < 4; c++) { D.eA[c] = NEG; D.bestA[c] = NEG; }
     int high = 0, pos = 0;
     // wave-uniform choice: do all 64 flanks cover every cell of both rows?  (steps 0..B)
-    const bool all_in = !INIT && __all((jlo <= 0) && (jhi >= B));
+    const bool all_in = !INIT && __all((n >= a.Nx) || ((jlo <= 0) && (jhi >= B)));   // padding lanes: all-N stream, masked vote
     if (all_in) run_band<INIT, false, CHAIN>(a, r, s_tab, Sin, Sout, bp, jlo, jhi, D, high, pos, buf, far, w0, w1, w2);
     else run_band<INIT, true, CHAIN>(a, r, s_tab, Sin, Sout, bp, jlo, jhi, D, high, pos, buf, far, w0, w1, w2);
     if (INIT || new_max) a.trim[n] = make_int2(high, pos);   // ram_extend.c:1203-1207 (913-914 at init)
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(BLOCK) void ramx_family_stream_kernel(const FSArgs 
         run_band<true, true, CHAIN>(a, r, s_tab, Sin, Sout, bp, jlo, jhi, D, high, pos, buf, far, w0, w1, w2);
       else
       {
-        const bool all_in = __all((jlo <= 0) && (jhi >= B));
+        const bool all_in = __all(!active || ((jlo <= 0) && (jhi >= B)));                // padding lanes: all-N stream, masked vote
         if (all_in) run_band<false, false, CHAIN>(a, r, s_tab, Sin, Sout, bp, jlo, jhi, D, high, pos, buf, far, w0, w1, w2);
         else run_band<false, true, CHAIN>(a, r, s_tab, Sin, Sout, bp, jlo, jhi, D, high, pos, buf, far, w0, w1, w2);
       }
