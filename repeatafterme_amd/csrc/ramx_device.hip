@@ -489,8 +489,6 @@ static int prk_plan(int tiles, int *block, int *blocks)
   if ((tiles + 3) / 4 <= cap)
   {
     *block = 256; *blocks = (tiles + 3) / 4;
-    const char *mb = getenv("RAMX_PRK_MIN_BLOCKS");      // experiment: pad the grid with workgroups that own no tile
-    if (mb && atoi(mb) > *blocks && atoi(mb) <= cap) *blocks = atoi(mb);
     return RAMX_OK;
   }
   if ((rc = prk_capacity_blocks<W, 512>(&cap)) != RAMX_OK) return rc;
