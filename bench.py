@@ -84,6 +84,9 @@ def main():
     ap.add_argument("--cpu-flanks", type=int, default=20000)
     ap.add_argument("--cpu-cols", type=int, default=200)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--ragged", type=float, default=0.0,
+                    help="development only: this fraction of the flanks ends early (uniform in [0, L)), so that waves "
+                         "take the far-end-masked band; the headline workload uses full-length flanks (0)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -146,6 +149,11 @@ def main():
     t0 = time.time()
     dev.load_library(fs.sequence)
     flanks, idx = resolve_flanks(1, fs.cores, W, L)
+    if args.ragged > 0:
+        rng = np.random.default_rng(7)
+        arr, nx = flanks
+        for i in np.nonzero(rng.random(nx) < args.ragged)[0]:
+            arr[int(i)].t_hi = min(arr[int(i)].t_hi, int(rng.integers(0, L)))
     dev.begin_direction(flanks, p)
     t_upload = time.time() - t0
 

@@ -546,6 +546,7 @@ static int prk_run(ramx_dev *d, const KArgs &a, int L, bool *used)
   }
   memcpy(pa.tab, a.tab, sizeof(pa.tab));
   pa.pack_ok = getenv("RAMX_NO_FASTPACK") ? 0 : fast_pack_ok(pa.tab, a.go, a.ge, L, W);
+  if (pa.pack_ok && getenv("RAMX_NO_MASKHI") == NULL) pa.pack_ok = 2;      // 2: the far-end-masked fast band may be used too
   HIPCHK(hipMemsetAsync(d->d_vote, 0, 3 * NSHARD * sizeof(PShard), d->stream));
   HIPCHK(hipMemsetAsync(d->d_err, 0, 64, d->stream));
   *used = true;
@@ -671,6 +672,7 @@ extern "C" int ramx_dev_run_families(ramx_dev *d, const ramx_flank *flanks, int3
     for (int k = 0; k < 4; k++) fa.tab[c][k] = p->matrix[k * 100 + code];
   }
   fa.pack_ok = getenv("RAMX_NO_FASTPACK") ? 0 : fast_pack_ok(fa.tab, fa.go, fa.ge, L, W);
+  if (fa.pack_ok && getenv("RAMX_NO_MASKHI") == NULL) fa.pack_ok = 2;
   HIPCHK(hipEventRecord(d->ev_begin, d->stream));
   // the shapes run side by side: one stream per class, forked from / joined into the library's stream
   if (!d->cls_init)
@@ -680,7 +682,9 @@ extern "C" int ramx_dev_run_families(ramx_dev *d, const ramx_flank *flanks, int3
     d->cls_init = 1;
   }
   HIPCHK(hipEventRecord(d->cls_ready, d->stream));
-  for (int c = 0; c < 4; c++) if (cls_count[c] > 0) HIPCHK(hipStreamWaitEvent(d->cls_stream[c], d->cls_ready, 0));
+  // every class stream waits (the register-resident branch below merges classes AFTER this point: a stream that is
+  // launched on must never have skipped the wait -- uploads and the pack kernel run on the library's stream)
+  for (int c = 0; c < 4; c++) HIPCHK(hipStreamWaitEvent(d->cls_stream[c], d->cls_ready, 0));
   if (!resident)
   {
     // rows of every family in the (in-place) row buffer: 16 B x (W + 1) slots per flank

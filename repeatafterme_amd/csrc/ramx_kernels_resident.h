@@ -164,8 +164,14 @@ __device__ __forceinline__ void fast_tabs_winner(FastTabs &ft, const int *tab_be
 // The four candidates take two cells per v_max3; their shared deletion term max_k e_k is folded in at the end.
 // The best cell of the row (value, lowest index on ties: bnw_extend.c:1020-1024) is tracked as a packed key
 // (m << 4) | (15 - (j & 15)) per 16-cell group, two cells per v_max3; exact while |m| < 2^27 (checked on the host).
-template <int W, int BLOCK>
-__device__ __forceinline__ void prk_band_fast(const int go, const int ge, const FastTabs &ft, short *sD, const int r,
+//
+// MASKHI: the same band for a wave in which some flank has run out at its far end (cells j > jhi out of bounds, every
+// cell in bounds on the near side, row >= W so that every fill is the sentinel, bnw_extend.c:990-1002).  Out-of-bounds
+// cells store (SENT, SENT + ge) exactly as the general band does; their candidate terms only have to stay negative
+// (the vote clamps at 0, ram_extend.c:1042) and their keys below every positive score (the best cell only matters when
+// it beats high >= 0): five extra VALU per cell instead of the general band's separate formulation.
+template <int W, int BLOCK, bool MASKHI>
+__device__ __forceinline__ void prk_band_fast(const int go, const int ge, const FastTabs &ft, short *sD, const int r, const int jhi,
                                               const unsigned (&w)[(2 * W + 1 + 8) / 8 + 2], int (&M)[2 * W + 1], LaneDP &D)
 {
   constexpr int B = 2 * W + 1, NG = (B + 15) / 16;
@@ -222,10 +228,12 @@ __device__ __forceinline__ void prk_band_fast(const int go, const int ge, const 
     for (int k = 0; k + 1 < PD; k++) { rowQ[k] = rowQ[k + 1]; dQ[k] = dQ[k + 1]; }
     if constexpr (j + PD <= B) rowQ[PD - 1] = fetch_row(std::integral_constant<int, (j + PD <= B ? j + PD : 0)>{});
     if constexpr (j + PD + 1 < B) dQ[PD - 1] = (int)myD[((j + PD + 1) >> 1) * (2 * BLOCK) + ((j + PD + 1) & 1)];
+    const bool inb = MASKHI ? (j <= jhi) : true;     // this step's cell of row r and candidate cell j-1 of row r+1
     // candidates' cell j-1 of row r+1: substitution from m_{j-1} of row r (the base of that cell is this step's)
     if constexpr (j >= 1)
     {
-      const int t4[4] = { add_sext_byte<0>(mPrev, sv), add_sext_byte<1>(mPrev, sv), add_sext_byte<2>(mPrev, sv), add_sext_byte<3>(mPrev, sv) };
+      const int ms = MASKHI ? (inb ? mPrev : SENT) : mPrev;
+      const int t4[4] = { add_sext_byte<0>(ms, sv), add_sext_byte<1>(ms, sv), add_sext_byte<2>(ms, sv), add_sext_byte<3>(ms, sv) };
       if constexpr ((j & 1) != 0)
       {
 #pragma unroll
@@ -243,11 +251,14 @@ __device__ __forceinline__ void prk_band_fast(const int go, const int ge, const 
       int Pe = NEG;
       if constexpr (j + 1 < B) Pe = M[j + 1] + dCur;
       const int sub = Pm + sF;                       // bnw_extend.c:950-956
-      const int m = vmax3(sub, eC, Pe);              // max(sub, max(ins, del)), :1007-1018
-      const int e = vmax3(sub + go, eC, Pe) + ge;
+      const int mr = vmax3(sub, eC, Pe);             // max(sub, max(ins, del)), :1007-1018
+      const int er = vmax3(sub + go, eC, Pe) + ge;
+      const int m = MASKHI ? (inb ? mr : SENT) : mr;                 // :990-1002
+      const int e = MASKHI ? (inb ? er : SENT + ge) : er;            // max(SENT + go, SENT) + ge with go <= 0
       M[j] = m;
       myD[(j >> 1) * (2 * BLOCK) + (j & 1)] = (short)(e - m);
-      const int key = (int)(((unsigned)m << 4) | (unsigned)(15 - (j & 15)));
+      const int kr = (int)(((unsigned)mr << 4) | (unsigned)(15 - (j & 15)));
+      const int key = MASKHI ? (inb ? kr : -2147483647 - 1) : kr;
       if constexpr ((j & 1) == 0 && j + 1 < B) kPend = key;
       else if constexpr ((j & 1) != 0) kg[j >> 4] = imax3(kg[j >> 4], kPend, key);
       else kg[j >> 4] = imax(kg[j >> 4], key);
@@ -288,7 +299,7 @@ __device__ __forceinline__ void prk_band(const int go, const int ge, const int *
   constexpr int B = 2 * W + 1;
   if (!OOB && !INIT)
   {
-    prk_band_fast<W, BLOCK>(go, ge, ft, sD, r, w, M, D);
+    prk_band_fast<W, BLOCK, false>(go, ge, ft, sD, r, 0, w, M, D);
     return;
   }
   const int edgeF = (r < W) ? go + (r + 1) * ge : SENT;
@@ -554,6 +565,8 @@ __global__ __launch_bounds__(BLOCK, 2) void ramx_persistent_kernel(const PArgs a
       // the masked path -- with N not a multiple of 64 that one slow wave would gate every column
       const bool all_in = a.pack_ok && __all((n >= a.Nx) || ((jlo <= 0) && (jhi >= B)));
       if (all_in) prk_band<W, false, BLOCK>(a.go, a.ge, s_tab, s_ft, sD, r, w, jlo, jhi, M, D);
+      else if (a.pack_ok > 1 && r >= W && __all((n >= a.Nx) || (jlo <= 0)))
+        prk_band_fast<W, BLOCK, true>(a.go, a.ge, s_ft, sD, r, jhi, w, M, D);      // some flank has run out at its far end
       else prk_band<W, true, BLOCK>(a.go, a.ge, s_tab, s_ft, sD, r, w, jlo, jhi, M, D);
       if (D.bestF > high) { high = D.bestF; pos = r + D.jbest - W; }   // ram_extend.c:1140-1150
       if (new_max) { thigh = high; tpos = pos; }                        // :1203-1207
@@ -756,6 +769,8 @@ __global__ __launch_bounds__(BLOCK, 2) void ramx_family_kernel(const FArgs a)
         // the masked path -- with N not a multiple of 64 that one slow wave would gate every column
         const bool all_in = a.pack_ok && __all((!active) || ((jlo <= 0) && (jhi >= B)));
         if (all_in) prk_band<W, false, BLOCK>(a.go, a.ge, s_tab, s_ft, sD, r, w, jlo, jhi, M, D);
+        else if (a.pack_ok > 1 && r >= W && __all(!active || (jlo <= 0)))
+          prk_band_fast<W, BLOCK, true>(a.go, a.ge, s_ft, sD, r, jhi, w, M, D);
         else prk_band<W, true, BLOCK>(a.go, a.ge, s_tab, s_ft, sD, r, w, jlo, jhi, M, D);
         if (D.bestF > high) { high = D.bestF; pos = r + D.jbest - W; }
         if (new_max) { thigh = high; tpos = pos; }
