@@ -5,6 +5,7 @@
  * the device path (ramx_extend_alignment).
  */
 #include <fcntl.h>
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -176,6 +177,29 @@ static void phase_done(const char *what)
   const double t = now_s();
   fprintf(stderr, "RAMX_TIMING %-18s %10.3f ms\n", what, (t - g_t_last) * 1e3);
   g_t_last = t;
+}
+
+/* The first HIP call of a process costs 0.1-0.3 s (runtime start-up, device context).  It does not depend on the
+ * input, so it runs in a helper thread while the loader reads the .2bit; joined before the first extension. */
+static pthread_t g_warm_thread;
+static int g_warm_started = 0;
+static void *warm_device(void *unused)
+{
+  (void)unused;
+  (void)ramx_default_device();          /* failure is reported by the main thread's own call later */
+  return NULL;
+}
+static void warm_join(void)
+{
+  if (g_warm_started) { g_warm_started = 0; pthread_join(g_warm_thread, NULL); }
+}
+static void warm_start(void)
+{
+  if (getenv("RAMX_NO_WARM_THREAD") == NULL && pthread_create(&g_warm_thread, NULL, warm_device, NULL) == 0)
+  {
+    g_warm_started = 1;
+    atexit(warm_join);                  /* every exit path (loader errors exit(255)) lets the runtime finish starting first */
+  }
 }
 
 /* everything the command line decides */
@@ -490,6 +514,7 @@ static int run_batch(struct cli_opts *o, time_t t_start)
   p.when_to_stop = o->when_to_stop; p.l = l; p.gapopen = o->sp->gapopen; p.gapextn = o->sp->gapextn; p.matrix = mflat;
   ramx_run_info *ir = (ramx_run_info *)calloc(F ? F : 1, sizeof(*ir)), *il = (ramx_run_info *)calloc(F ? F : 1, sizeof(*il));
 
+  warm_join();
   /* phase 2: right extension of all families in one launch; phase 3: per family, overlap avoidance */
   for (size_t i = 0; i < F; i++) flatten_cores(it[i].cores, it[i].N, &fam[i].cores);
   if (ramx_extend_batch(1, fam, (int32_t)F, &p, ir) < 0) { fprintf(stderr, "RAMExtend(ramx): batch extension failed: %s\n", ramx_last_error()); exit(1); }
@@ -603,6 +628,7 @@ int ramx_cli_main(int argc, char **argv)
     }
     usage();
   }
+  warm_start();
   if (o.batch_file) return run_batch(&o, t_start);
 
   g_timing = getenv("RAMX_TIMING") != NULL;
@@ -628,6 +654,8 @@ int ramx_cli_main(int argc, char **argv)
 
   ramx_set_runtime(o.verbose, o.when_to_stop, l);
   fflush(stdout);
+  warm_join();
+  phase_done("device ready");
   int rightbp = ramx_extend_alignment(1, cores, NULL, lib, master, o.bandwidth, o.cappenalty, o.minimprovement, L, N, o.sp, NULL);
   printf("Extended right: %d bp\n", rightbp);
   phase_done("extend right");
