@@ -163,9 +163,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    import hashlib
+
+    def result_digest():
+        cons, th, tp = dev.download()
+        return hashlib.sha1(np.ascontiguousarray(cons).tobytes() + np.ascontiguousarray(th).tobytes()
+                            + np.ascontiguousarray(tp).tobytes()).hexdigest()
+
     infos = []
+    digest0 = None
     for _ in range(args.warmup):
         dev.run_direction()
+        digest0 = result_digest()
     barrier()
     t0 = time.perf_counter()
     for s in range(args.steps):
@@ -176,6 +185,13 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+
+    # outside the timed region: every pass over the same resident input must give the same consensus and the same
+    # per-flank trimmed scores / positions (a race in the vote or the barrier would show up here)
+    digest1 = result_digest()
+    repeatable = (digest0 is None) or (digest0 == digest1)
+    if not repeatable:
+        raise SystemExit(f"bench: results of the timed passes differ from the warm-up pass ({digest0} vs {digest1})")
 
     cols = sum(i.rows_executed for i in infos)
     total_flanks = N * world
@@ -222,6 +238,7 @@ def main():
                                           else "registered host shared memory over PCIe)")) if (peer_path and persistent)
                                       else "all-reduced with RCCL between column launches")) if world > 1 else "single GPU"},
         "columns_per_sec": cols / dt,
+        "checks": {"result_sha1": digest1, "same_as_warmup_pass": bool(digest0 is not None)},
         "cell_updates_per_sec": cols / dt * total_flanks * (2 * W + 1) * 4,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
