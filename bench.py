@@ -217,12 +217,25 @@ def main():
         abytes = per_col_bytes
     achieved = abytes / (kavg_ms * 1e-3) / 1e9 if kavg_ms > 0 else 0.0
     traffic = None
+    valu = None
     pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
     if os.path.exists(pmc):
         try:
             ent = json.load(open(pmc)).get("persistent" if persistent else "column", {})
             per_col = ent.get("hbm_bytes_per_column")
             traffic = per_col * rows / n_launch if (per_col is not None and persistent) else per_col
+            # what actually bounds the persistent kernel: VALU issue.  Instructions per column from the same PMC pass
+            # (SQ_INSTS_VALU over the profiled launch's columns), time per column measured live; a wave64 VALU
+            # instruction occupies its SIMD for 4 cycles, 1,024 SIMDs at the 2.4 GHz peak engine clock.
+            cnt = ent.get("avg_per_dispatch", {})
+            if persistent and per_col and cnt.get("SQ_INSTS_VALU") and ent.get("hbm_bytes_per_launch"):
+                cols_prof = ent["hbm_bytes_per_launch"] / per_col
+                valu_per_col = cnt["SQ_INSTS_VALU"] / cols_prof
+                us_col = loop_ms * 1e3 / max(rows, 1)
+                valu = {"insts_per_column": valu_per_col,
+                        "issue_frac_whole_chip": valu_per_col * 4 / (1024 * 2.4e3 * us_col),
+                        "note": "secondary roof: share of all VALU issue slots (256 CUs) used over the whole column, "
+                                "barrier wait included; 196 of 256 CUs hold workgroups at N = 100,000"}
         except Exception:
             traffic = None
     out = {
@@ -245,7 +258,7 @@ def main():
                      "kernel": kernel, "kernel_avg_us": kavg_ms * 1e3, "launches_timed": n_launch,
                      "us_per_column": loop_ms * 1e3 / max(rows, 1),
                      "algorithmic_bytes_per_flank_column": algorithmic_bytes_per_flank_column(W),
-                     "algorithmic_bytes_per_launch": abytes,
+                     "algorithmic_bytes_per_launch": abytes, "valu": valu,
                      "note": ("rows stay in registers/LDS for the whole launch: HBM traffic is far below the algorithmic "
                               "bytes, so achieved exceeds the HBM peak; the kernel is VALU/barrier bound (DESIGN.md 4.2)")
                              if persistent else "streaming kernel: one launch per column"},
