@@ -66,3 +66,23 @@ def test_forced_full_length_run_is_deterministic(family):
         assert r.rows_executed == L and r.ret == K
         outs.append((m.copy(), c.right_len.copy(), c.score.copy()))
     assert all(np.array_equal(x, y) for x, y in zip(*outs))
+
+
+@pytest.mark.parametrize("n,route", [(150, "one workgroup"), (1500, "device-wide")])
+def test_wrapper_configuration_long_L(n, route):
+    """The configuration the reference's wrapper runs (util/extend-stk.pl:352): -L 20000 -bandwidth 40, matrix by
+    divergence, -minimprovement 30; a few thousand columns execute before the stop rule ends the run.  Both routes of
+    seam 1 (batch of one / persistent kernel) against the oracle, both directions."""
+    Lw = 20000
+    fs = synth_family(n, Lw, 40, K=2600, seed=321 + n, both_sides=True, minus_frac=0.35, n_run_frac=0.05)
+    p = po.Params.named("18p43g", bandwidth=40, L=Lw, when_to_stop=100, minimprovement=30)
+    c1, c2 = fs.cores.copy(), fs.cores.copy()
+    m1, m2 = new_master(Lw), new_master(Lw)
+    want = [po.oracle_extend(d, c1, fs.sequence, m1, p) for d in (1, 0)]
+    got = [gpu_extend(d, c2, fs.sequence, m2, p) for d in (1, 0)]
+    for a, b in zip(want, got):
+        assert (a.ret, a.rows_executed, a.limit_warning) == (b.ret, b.rows_executed, b.limit_warning), route
+        assert a.rows_executed > 2500
+    assert np.array_equal(m1, m2), route
+    assert np.array_equal(c1.left_len, c2.left_len) and np.array_equal(c1.right_len, c2.right_len), route
+    assert np.array_equal(c1.score, c2.score), route
