@@ -105,6 +105,7 @@ struct ramx_dev
   PeerBox *xbox; PeerBox *peer[RAMX_MAX_RANKS]; PeerBox **d_peer; int peer_ready;
   // host-memory variant of the boxes (POSIX shared memory registered with HIP): xbox/peer point into it
   void *hostbox_map; size_t hostbox_bytes; PeerBox *hostbox_host; int hostbox_registered;
+  PeerBox *hostbox_mirror;   // device-memory copy of my host box, kept current by block 0 (the other blocks poll it)
   PeerBox *devbox;     // this rank's fine-grained device-memory box (exported over hipIpc)
   hipStream_t cls_stream[4]; hipEvent_t cls_ready, cls_done[4]; int cls_init;   // batch mode: one stream per workgroup shape
   int force_chain;   // RAMX_FORCE_CHAIN=1: always run the full candidate recurrence (test hook)
@@ -171,6 +172,7 @@ extern "C" void ramx_dev_destroy(ramx_dev *d)
     (void)hipEventDestroy(d->cls_ready);
   }
   if (d->devbox) (void)hipFree(d->devbox);
+  if (d->hostbox_mirror) (void)hipFree(d->hostbox_mirror);
   if (d->d_peer) (void)hipFree(d->d_peer);
   for (int i = 0; i < 2; i++) (void)hipEventDestroy(d->ev_chk[i]);
   (void)hipEventDestroy(d->ev_begin); (void)hipEventDestroy(d->ev_end);
@@ -533,6 +535,13 @@ static int prk_run(ramx_dev *d, const KArgs &a, int L, bool *used)
   if (multi)
   {
     pa.nranks = d->nranks; pa.rank = d->rank; pa.peers = (PeerBox *const *)d->d_peer; pa.box = d->xbox;
+    pa.mirror = NULL;
+    if (d->hostbox_host)
+    {
+      if (!d->hostbox_mirror) HIPCHK(hipMalloc((void **)&d->hostbox_mirror, sizeof(PeerBox)));
+      HIPCHK(hipMemsetAsync(d->hostbox_mirror, 0, sizeof(PeerBox), d->stream));
+      pa.mirror = d->hostbox_mirror;
+    }
     // my box is cleared BEFORE the collective below, which no remote launch can get past without my taking part:
     // nobody writes a word of this run into it too early, and nothing of the last run survives
     if (d->hostbox_host)

@@ -54,6 +54,8 @@ struct PArgs
   unsigned *err;                // != 0: a bounded spin gave up
   PeerBox *const *peers;        // [nranks] every rank's box as seen from this device (NULL on one GPU)
   PeerBox *box;                 // this rank's own box
+  PeerBox *mirror;              // host-memory boxes only: a device-memory copy of `box` that block 0 keeps current, so that
+                                // ONE workgroup polls across PCIe and the others poll locally (NULL: everybody polls `box`)
   int rank, nranks;
   int Np, Nx, r0, L, go, ge, cap, minimp, when_to_stop, nblocks;
   int tab[RAMX_NCLASS][4];
@@ -480,13 +482,21 @@ __global__ __launch_bounds__(BLOCK, 2) void ramx_persistent_kernel(const PArgs a
         unsigned long long y[4] = { 0, 0, 0, 0 };
         bool got = lane >= a.nranks;
         unsigned spins = 0;
+        const PeerBox *pollbox = (a.mirror != NULL && blockIdx.x != 0) ? a.mirror : a.box;
         for (;;)
         {
           if (!got)
           {
 #pragma unroll
-            for (int k = 0; k < 4; k++) y[k] = __hip_atomic_load(&a.box->slot[r % 3][lane][k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            for (int k = 0; k < 4; k++) y[k] = __hip_atomic_load(&pollbox->slot[r % 3][lane][k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             got = (y[0] >> 48) == (tag >> 48) && (y[1] >> 48) == (tag >> 48) && (y[2] >> 48) == (tag >> 48) && (y[3] >> 48) == (tag >> 48);
+            if (got && a.mirror != NULL && blockIdx.x == 0)
+            {
+              // this rank's word of this column has arrived: pass it on to the local pollers
+#pragma unroll
+              for (int k = 0; k < 4; k++)
+                __hip_atomic_store(&a.mirror->slot[r % 3][lane][k], y[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
           }
           if (__all(got)) break;
           if (++spins > PRK_SPIN_LIMIT || ((spins & 1023u) == 0 && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0))
