@@ -30,6 +30,10 @@ int ramx_runtime_l(void) { return g_l; }
 static ramx_dev *g_dev = NULL;
 static const int8_t *g_lib_ptr = NULL;
 static uint64_t g_lib_len = 0;
+/* batch mode: the (pointer, length) of every family whose concatenation the device currently holds */
+static const int8_t **g_bl_ptr = NULL;
+static uint64_t *g_bl_len = NULL;
+static int g_bl_n = 0;
 
 ramx_dev *ramx_default_device(void)
 {
@@ -290,19 +294,29 @@ int ramx_extend_batch(int direction, ramx_family *fam, int32_t F, const ramx_par
     take[f] = batchable && nx <= 512;
     if (take[f]) { total_len += fam[f].seq_len; total_pad += (size_t)((nx + 63) / 64) * 64; }
   }
-  int8_t *lib = (int8_t *)malloc(total_len ? total_len : 1);
+  /* The concatenated library holds EVERY family at a fixed offset (prefix sums of seq_len), so it is the same for both
+   * directions: like seam 1, it is built and uploaded again only when a family's (pointer, length) changes. */
+  uint64_t *at_of = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)(F ? F : 1));
+  total_len = 0;
+  for (int f = 0; f < F; f++) { at_of[f] = total_len; total_len += fam[f].seq_len; }
+  int lib_cached = (g_lib_ptr == (const int8_t *)&g_bl_n) && g_bl_n == F && g_lib_len == total_len;
+  for (int f = 0; f < F && lib_cached; f++)
+    if (g_bl_ptr[f] != fam[f].sequence || g_bl_len[f] != fam[f].seq_len) lib_cached = 0;
+  int8_t *lib = lib_cached ? NULL : (int8_t *)malloc(total_len ? total_len : 1);
   ramx_flank *fl = (ramx_flank *)malloc(sizeof(ramx_flank) * (total_pad ? total_pad : 1));
   int32_t *map = (int32_t *)malloc(sizeof(int32_t) * (total_pad ? total_pad : 1));
   int32_t *first = (int32_t *)malloc(sizeof(int32_t) * (size_t)(F ? F : 1));
   int32_t *count = (int32_t *)malloc(sizeof(int32_t) * (size_t)(F ? F : 1));
   int32_t *fidx = (int32_t *)malloc(sizeof(int32_t) * (size_t)(F ? F : 1));
-  uint64_t at = 0;
   size_t fpos = 0;
   int nb = 0;
+  if (lib)
+    for (int f = 0; f < F; f++)
+      if (fam[f].seq_len) memcpy(lib + at_of[f], fam[f].sequence, fam[f].seq_len);
   for (int f = 0; f < F; f++)
   {
     if (!take[f]) continue;
-    if (fam[f].seq_len) memcpy(lib + at, fam[f].sequence, fam[f].seq_len);
+    const uint64_t at = at_of[f];
     ramx_flank *tmp = (ramx_flank *)malloc(sizeof(ramx_flank) * (size_t)(fam[f].cores.n > 0 ? fam[f].cores.n : 1));
     int32_t *tmap = (int32_t *)malloc(sizeof(int32_t) * (size_t)(fam[f].cores.n > 0 ? fam[f].cores.n : 1));
     const int nx = ramx_resolve_flanks(direction, &fam[f].cores, W, L, tmp, tmap);
@@ -310,7 +324,6 @@ int ramx_extend_batch(int direction, ramx_family *fam, int32_t F, const ramx_par
     for (int i = 0; i < nx; i++) { fl[fpos] = tmp[i]; fl[fpos].start += (int64_t)at; map[fpos] = tmap[i]; fpos++; }
     while (fpos & 63) { memset(&fl[fpos], 0, sizeof(ramx_flank)); fl[fpos].t_lo = 1; fl[fpos].t_hi = 0; fl[fpos].step = 1; map[fpos] = -1; fpos++; }
     free(tmp); free(tmap);
-    at += fam[f].seq_len;
     nb++;
   }
   if (nb > 0)
@@ -319,8 +332,20 @@ int ramx_extend_batch(int direction, ramx_family *fam, int32_t F, const ramx_par
     int8_t *cons = (int8_t *)malloc((size_t)nb * (size_t)(L > 0 ? L : 1));
     int32_t *th = (int32_t *)malloc(sizeof(int32_t) * (fpos ? fpos : 1));
     int32_t *tp = (int32_t *)malloc(sizeof(int32_t) * (fpos ? fpos : 1));
-    g_lib_ptr = NULL; g_lib_len = 0;                 /* the cached single-family library is replaced */
-    rc = ramx_dev_load_library(d, lib, at);
+    if (!lib_cached)
+    {
+      g_lib_ptr = NULL; g_lib_len = 0;               /* whatever library the device held is replaced */
+      rc = ramx_dev_load_library(d, lib, total_len);
+      if (rc == RAMX_OK)
+      {
+        g_bl_ptr = (const int8_t **)realloc((void *)g_bl_ptr, sizeof(*g_bl_ptr) * (size_t)(F ? F : 1));
+        g_bl_len = (uint64_t *)realloc(g_bl_len, sizeof(*g_bl_len) * (size_t)(F ? F : 1));
+        for (int f = 0; f < F; f++) { g_bl_ptr[f] = fam[f].sequence; g_bl_len[f] = fam[f].seq_len; }
+        g_bl_n = F;
+        g_lib_ptr = (const int8_t *)&g_bl_n;         /* sentinel: the device holds the batch library described by g_bl_* */
+        g_lib_len = total_len;
+      }
+    }
     if (rc == RAMX_OK) rc = ramx_dev_run_families(d, fl, (int32_t)fpos, first, count, nb, p, binfo, cons, th, tp);
     if (rc == RAMX_OK)
     {
@@ -356,7 +381,7 @@ int ramx_extend_batch(int direction, ramx_family *fam, int32_t F, const ramx_par
     int r1 = ramx_extend_flat(direction, &fam[f].cores, fam[f].sequence, fam[f].seq_len, fam[f].master, p, &infos[f]);
     if (r1 < 0) rc = r1;
   }
-  free(lib); free(fl); free(map); free(first); free(count); free(fidx); free(take); free(own);
+  free(lib); free(at_of); free(fl); free(map); free(first); free(count); free(fidx); free(take); free(own);
   return rc;
 }
 
