@@ -91,7 +91,8 @@ struct ramx_dev
   long long *d_sums; RamxCtl *d_ctl; signed char *d_cons;
   PShard *d_vote; unsigned *d_err;   // persistent kernel: fused vote / barrier words
   int last_persistent;
-  size_t cap_flanks, cap_bases, cap_state, cap_cons;
+  size_t cap_flanks, cap_bases, cap_state, cap_cons, cap_bounds, cap_trim, cap_fam, cap_famctl;
+  void *d_fam; RamxCtl *d_famctl;    // batch mode: family descriptors / per-family control blocks (kept between calls)
   RamxCtl *h_ctl;   // pinned, [2 checkpoints][2 slots]
   hipEvent_t ev_chk[2], ev_begin, ev_end, ev_s0[MAX_SAMPLES], ev_s1[MAX_SAMPLES];
   int Nx, Np, KW;
@@ -172,6 +173,7 @@ extern "C" void ramx_dev_destroy(ramx_dev *d)
     (void)hipEventDestroy(d->cls_ready);
   }
   if (d->devbox) (void)hipFree(d->devbox);
+  (void)hipFree(d->d_fam); (void)hipFree(d->d_famctl);
   if (d->hostbox_mirror) (void)hipFree(d->hostbox_mirror);
   if (d->d_peer) (void)hipFree(d->d_peer);
   for (int i = 0; i < 2; i++) (void)hipEventDestroy(d->ev_chk[i]);
@@ -230,10 +232,8 @@ extern "C" int ramx_dev_begin_direction(ramx_dev *d, const ramx_flank *flanks, i
   int rc;
   if ((rc = ensure(&d->d_flanks, &d->cap_flanks, (size_t)Np * sizeof(ramx_flank)))) return rc;
   if ((rc = ensure(&d->d_bases, &d->cap_bases, (size_t)KW * Np * sizeof(unsigned)))) return rc;
-  if (d->d_bounds) { HIPCHK(hipFree(d->d_bounds)); d->d_bounds = NULL; }
-  if (d->d_trim) { HIPCHK(hipFree(d->d_trim)); d->d_trim = NULL; }
-  HIPCHK(hipMalloc((void **)&d->d_bounds, (size_t)Np * sizeof(int2)));
-  HIPCHK(hipMalloc((void **)&d->d_trim, (size_t)Np * sizeof(int2)));
+  if ((rc = ensure(&d->d_bounds, &d->cap_bounds, (size_t)Np * sizeof(int2)))) return rc;   // kept between calls: hipFree/hipMalloc
+  if ((rc = ensure(&d->d_trim, &d->cap_trim, (size_t)Np * sizeof(int2)))) return rc;       // per call cost ~0.5 ms of device sync
   const size_t state_bytes = (size_t)Np * Q * sizeof(int4);
   if (state_bytes > d->cap_state || !d->d_state[0])
   {
@@ -641,10 +641,8 @@ extern "C" int ramx_dev_run_families(ramx_dev *d, const ramx_flank *flanks, int3
   int rc;
   if ((rc = ensure(&d->d_flanks, &d->cap_flanks, (size_t)Np * sizeof(ramx_flank)))) return rc;
   if ((rc = ensure(&d->d_bases, &d->cap_bases, (size_t)KW * Np * sizeof(unsigned)))) return rc;
-  if (d->d_bounds) { HIPCHK(hipFree(d->d_bounds)); d->d_bounds = NULL; }
-  if (d->d_trim) { HIPCHK(hipFree(d->d_trim)); d->d_trim = NULL; }
-  HIPCHK(hipMalloc((void **)&d->d_bounds, (size_t)Np * sizeof(int2)));
-  HIPCHK(hipMalloc((void **)&d->d_trim, (size_t)Np * sizeof(int2)));
+  if ((rc = ensure(&d->d_bounds, &d->cap_bounds, (size_t)Np * sizeof(int2)))) return rc;   // kept between calls: hipFree/hipMalloc
+  if ((rc = ensure(&d->d_trim, &d->cap_trim, (size_t)Np * sizeof(int2)))) return rc;       // per call cost ~0.5 ms of device sync
   if ((rc = ensure(&d->d_cons, &d->cap_cons, (size_t)n_families * (L > 0 ? L : 1) + 16))) return rc;
   // descriptors grouped by workgroup shape (64, 128, 256, 512 threads = 1, 2, 4, 8 tiles): one launch per non-empty
   // class, so a 100-flank family occupies two waves, not four
@@ -661,9 +659,9 @@ extern "C" int ramx_dev_run_families(ramx_dev *d, const ramx_flank *flanks, int3
       x.tile0 = fam_first[f] / 64; x.ntiles = (fam_count[f] + 63) / 64; x.nx = fam_count[f]; x.id = f;
     }
   }
-  FamDesc *dfd = NULL; RamxCtl *dctl = NULL;
-  HIPCHK(hipMalloc((void **)&dfd, sizeof(FamDesc) * n_families));
-  HIPCHK(hipMalloc((void **)&dctl, sizeof(RamxCtl) * n_families));
+  if ((rc = ensure(&d->d_fam, &d->cap_fam, sizeof(FamDesc) * (size_t)n_families))) { free(hfd); return rc; }
+  if ((rc = ensure(&d->d_famctl, &d->cap_famctl, sizeof(RamxCtl) * (size_t)n_families))) { free(hfd); return rc; }
+  FamDesc *dfd = (FamDesc *)d->d_fam; RamxCtl *dctl = d->d_famctl;
   HIPCHK(hipMemcpyAsync(dfd, hfd, sizeof(FamDesc) * n_families, hipMemcpyHostToDevice, d->stream));
   if (n_padded) HIPCHK(hipMemcpyAsync(d->d_flanks, flanks, (size_t)n_padded * sizeof(ramx_flank), hipMemcpyHostToDevice, d->stream));
   dim3 grid((Np + 255) / 256, KW);
@@ -770,7 +768,6 @@ extern "C" int ramx_dev_run_families(ramx_dev *d, const ramx_flank *flanks, int3
     infos[f].persistent = resident ? 1 : 2;     /* 2: streaming family kernel */
   }
   free(hctl); free(hfd);
-  (void)hipFree(dfd); (void)hipFree(dctl);
   d->ready = 0;       // the single-family buffers were reused: begin_direction must be called again before run_direction
   return RAMX_OK;
 }
