@@ -680,6 +680,10 @@ extern "C" int ramx_dev_run_families(ramx_dev *d, const ramx_flank *flanks, int3
   }
   fa.pack_ok = getenv("RAMX_NO_FASTPACK") ? 0 : fast_pack_ok(fa.tab, fa.go, fa.ge, L, W);
   if (fa.pack_ok && getenv("RAMX_NO_MASKHI") == NULL) fa.pack_ok = 2;
+#ifdef RAMX_PRK_TIMING
+  HIPCHK(hipMalloc((void **)&fa.dbg, 8 * 8 * sizeof(unsigned long long)));
+  HIPCHK(hipMemset(fa.dbg, 0, 8 * 8 * sizeof(unsigned long long)));
+#endif
   HIPCHK(hipEventRecord(d->ev_begin, d->stream));
   // the shapes run side by side: one stream per class, forked from / joined into the library's stream
   if (!d->cls_init)
@@ -745,6 +749,20 @@ extern "C" int ramx_dev_run_families(ramx_dev *d, const ramx_flank *flanks, int3
   HIPCHK(hipStreamSynchronize(d->stream));
   float ms = 0;
   HIPCHK(hipEventElapsedTime(&ms, d->ev_begin, d->ev_end));
+#ifdef RAMX_PRK_TIMING
+  if (resident)
+  {
+    unsigned long long h[64];
+    HIPCHK(hipMemcpy(h, fa.dbg, sizeof(h), hipMemcpyDeviceToHost));
+    static const char *nm[6] = { "vote + stop rule", "winner table+barrier", "band + contrib", "wave reduce", "end barrier", "loop top" };
+    const double cols = h[6] ? (double)h[6] : 1.0;
+    fprintf(stderr, "FAM_TIMING family 0 (block 0), %.0f columns, ns per column per wave:\n", cols);
+    for (int k = 0; k < 6; k++)
+      fprintf(stderr, "FAM_TIMING %-22s w0 %7.1f  w1 %7.1f  w2 %7.1f  w3 %7.1f\n", nm[k], 10.0 * h[k] / cols, 10.0 * h[8 + k] / cols,
+              10.0 * h[16 + k] / cols, 10.0 * h[24 + k] / cols);
+    (void)hipFree(fa.dbg);
+  }
+#endif
   RamxCtl *hctl = (RamxCtl *)malloc(sizeof(RamxCtl) * n_families);
   HIPCHK(hipMemcpy(hctl, dctl, sizeof(RamxCtl) * n_families, hipMemcpyDeviceToHost));
   if (cons && L > 0) HIPCHK(hipMemcpy(cons, d->d_cons, (size_t)n_families * L, hipMemcpyDeviceToHost));

@@ -669,6 +669,7 @@ struct FArgs
   int Np, L, go, ge, cap, minimp, when_to_stop;
   int tab[RAMX_NCLASS][4];
   int pack_ok;
+  unsigned long long *dbg;      // -DRAMX_PRK_TIMING builds only
 };
 
 template <int W, int BLOCK>
@@ -720,8 +721,12 @@ __global__ __launch_bounds__(BLOCK, 2) void ramx_family_kernel(const FArgs a)
 #pragma unroll
     for (int k = 0; k < NW; k++) w[k] = bp[(size_t)k * a.Np];
   }
+#ifdef RAMX_PRK_TIMING
+  unsigned long long tsum[6] = { 0, 0, 0, 0, 0, 0 }, tlast = wall_clock64();
+#endif
   for (int r = -1; r < a.L; r++)
   {
+    PRK_TICK(5);
     if (r >= 0 && ((r + 8) & 7) == 0)
     {
 #pragma unroll
@@ -760,8 +765,10 @@ __global__ __launch_bounds__(BLOCK, 2) void ramx_family_kernel(const FArgs a)
     if (r >= 0 && a.pack_ok)
     {
       // winner rows of the fast-path tables; everybody has left the previous column's band (barrier at its end)
+      PRK_TICK(0);               // vote folded, stop rule
       fast_tabs_winner(s_ft, s_tab, threadIdx.x);
       __syncthreads();
+      PRK_TICK(1);               // winner table + barrier
     }
     int contrib[4] = { 0, 0, 0, 0 };
     if (live)
@@ -796,6 +803,7 @@ __global__ __launch_bounds__(BLOCK, 2) void ramx_family_kernel(const FArgs a)
         }
       }
     }
+    PRK_TICK(2);                 // band + contributions
     if (stopped || r == a.L - 1) break;
     {
       long long tot[4];
@@ -807,8 +815,18 @@ __global__ __launch_bounds__(BLOCK, 2) void ramx_family_kernel(const FArgs a)
         for (int c = 0; c < 4; c++) s_red[(r + 1) & 1][wave][c] = tot[c];
       }
     }
+    PRK_TICK(3);                 // wave reduction + LDS write
     __syncthreads();
+    PRK_TICK(4);                 // end-of-column barrier
   }
+#ifdef RAMX_PRK_TIMING
+  if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && a.dbg != NULL)
+  {
+#pragma unroll
+    for (int k = 0; k < 6; k++) a.dbg[wave * 8 + k] = tsum[k];
+    a.dbg[wave * 8 + 6] = (unsigned long long)rows_done;
+  }
+#endif
   if (live) a.trim[n] = make_int2(thigh, tpos);
   if (threadIdx.x == 0)
   {
