@@ -224,6 +224,11 @@ def main():
             ent = json.load(open(pmc)).get("persistent" if persistent else "column", {})
             per_col = ent.get("hbm_bytes_per_column")
             traffic = per_col * rows / n_launch if (per_col is not None and persistent) else per_col
+            fit = json.load(open(pmc)).get("persistent_fit")
+            if persistent and fit:
+                # two PMC launches of different length (tools/pmc_traffic_fit.sh): rows in and out once per launch +
+                # the base stream per column
+                traffic = fit["fixed_bytes_per_launch"] + fit["bytes_per_column"] * rows / n_launch
             # what actually bounds the persistent kernel: VALU issue.  Instructions per column from the same PMC pass
             # (SQ_INSTS_VALU over the profiled launch's columns), time per column measured live; a wave64 VALU
             # instruction occupies its SIMD for 4 cycles, 1,024 SIMDs at the 2.4 GHz peak engine clock.
