@@ -134,6 +134,7 @@ typedef struct ramx_run_info
   int32_t kernel_samples;
   double  prep_ms;          /* host flatten + H2D + pack kernel (wall clock) */
   int32_t persistent;       /* 1: the whole loop ran as ONE persistent launch (rows resident on chip) */
+  int32_t lanes_per_flank;  /* 1: one lane per flank; 2..16: the cell-parallel kernels split a band row over that many lanes */
 } ramx_run_info;
 
 int ramx_extend_flat(int direction, ramx_flat_cores *cores, const int8_t *sequence, uint64_t seq_len,
@@ -194,6 +195,12 @@ int ramx_dev_download(ramx_dev *d, int8_t *cons, int32_t cons_cap, int32_t *trim
 /* debug / test hook: current DP row state of one flank as [2W+1][2] int32 + high,pos.  The device stores each
  * cell transformed: (m, e) = (max(sub,gap), max(sub+gapopen,gap)+gapextn) -- see csrc/ramx_kernels_common.h. */
 int ramx_dev_peek_state(ramx_dev *d, int32_t flank, int32_t *cells, int32_t *high, int32_t *pos);
+
+/* debug / test hook: with RAMX_CP_PEEK=1 in the environment the cell-parallel family kernel keeps the final DP row of
+ * every flank of the last ramx_dev_run_families call; cells receives [2W+1][2] int32 in the (m, e) encoding of
+ * ramx_dev_peek_state.  `flank` indexes the (padded) flank array of that call; d == NULL means the process-wide
+ * session that seam 1 (ramx_extend_flat / ramx_extend_batch) runs on. */
+int ramx_dev_peek_family_state(ramx_dev *d, int32_t flank, int32_t *cells);
 
 /* Batch mode (no counterpart in the reference, whose wrapper util/extend-stk.pl:242-371 starts one
  * RAMExtend process per family): many families in ONE launch, one workgroup per family, every family with its own

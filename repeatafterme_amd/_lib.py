@@ -13,7 +13,7 @@ CLI_PATH = os.path.join(_PKG, "RAMExtend")
 EXPORTS = [
     "ramx_set_runtime", "ramx_extend_alignment", "ramx_extend_flat", "ramx_resolve_flanks", "ramx_last_error", "ramx_device_count",
     "ramx_dev_create", "ramx_dev_destroy", "ramx_dev_load_library", "ramx_dev_begin_direction",
-    "ramx_dev_run_direction", "ramx_dev_download", "ramx_dev_peek_state", "ramx_dev_run_families", "ramx_extend_batch", "ramx_comm_unique_id",
+    "ramx_dev_run_direction", "ramx_dev_download", "ramx_dev_peek_state", "ramx_dev_peek_family_state", "ramx_dev_run_families", "ramx_extend_batch", "ramx_comm_unique_id",
     "ramx_dev_comm_init", "ramx_dev_set_allreduce_cb", "ramx_dev_peer_export", "ramx_dev_peer_import",
     "ramx_dev_peer_selftest", "ramx_dev_peer_enable", "ramx_dev_hostbox_attach", "ramx_hostbox_unlink", "ramx_get_matrix", "ramx_get_matrix_using_gap_penalties",
     "ramx_get_repeatscout_matrix", "ramx_free_scoring_system", "ramx_calculate_lambda",
@@ -41,7 +41,7 @@ class RunInfo(C.Structure):
     _fields_ = [("ret", C.c_int32), ("rows_executed", C.c_int32), ("limit_warning", C.c_int32),
                 ("overflow32", C.c_int32), ("n_extendable", C.c_int32), ("launches", C.c_int32),
                 ("loop_ms", C.c_double), ("kernel_ms_avg", C.c_double), ("kernel_samples", C.c_int32),
-                ("prep_ms", C.c_double), ("persistent", C.c_int32)]
+                ("prep_ms", C.c_double), ("persistent", C.c_int32), ("lanes_per_flank", C.c_int32)]
 
 
 class Family(C.Structure):
@@ -92,6 +92,7 @@ def lib() -> C.CDLL:
         L.ramx_dev_download.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
         L.ramx_dev_peek_state.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(C.c_int32),
                                           C.POINTER(C.c_int32)]
+        L.ramx_dev_peek_family_state.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
         L.ramx_comm_unique_id.argtypes = [C.c_void_p]
         L.ramx_dev_comm_init.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         L.ramx_dev_set_allreduce_cb.argtypes = [C.c_void_p, ALLREDUCE_CB, C.c_void_p]

@@ -1,0 +1,86 @@
+// ramx_cp.hip -- second translation unit of libramx's device code: the cell-parallel kernels (ramx_kernels_cp.h) and
+// their launchers.  Kept apart from ramx_device.hip so that the two compile side by side.
+#define RAMX_SECONDARY_TU 1
+#include "ramx_kernels_cp.h"
+
+#include <stdlib.h>
+
+#define CP_MAX_CELLS 21      // cells per lane up to which the row (2 registers per cell) and its temporaries fit 128 VGPRs
+
+static bool cp_has_width(int W) { return W == 14 || W == 20 || W == 40 || W == 80; }
+static int cp_cells(int W, int K) { return (2 * W + 1 + K - 1) / K; }
+
+int ramx_cp_max_family(int W, int go, int ge, const int (&tab)[RAMX_NCLASS][4], int L)
+{
+  if (!cp_has_width(W) || go > 0 || ge > 0 || L <= 0 || getenv("RAMX_NO_CP") != NULL) return 0;
+  long long mx = (long long)(-go) + (long long)(-ge);
+  for (int c = 0; c < RAMX_NCLASS; c++)
+    for (int k = 0; k < 4; k++)
+    {
+      if (tab[c][k] < -128 || tab[c][k] > 127) return 0;
+      const long long v = tab[c][k] < 0 ? -(long long)tab[c][k] : (long long)tab[c][k];
+      if (v > mx) mx = v;
+    }
+  // a row-r cell is at most (r + W + 2) steps of at most mx away from 0; keys hold (score << 8 | cell); block totals are
+  // tilted by up to 16 * C * |ge|
+  if (((long long)L + 2LL * W + 4) * mx >= (1LL << 23)) return 0;
+  if (-(long long)ge * 200 >= (1LL << 23)) return 0;
+  int best = 0;
+  for (int K = 16; K >= 2; K >>= 1)
+    if (cp_cells(W, K) <= CP_MAX_CELLS) best = 1024 / K;
+  return best;
+}
+
+int ramx_cp_class(int W, int nx, int *K, int *threads)
+{
+  static const int cls_nx[RAMX_CP_NCLASS] = { 16, 32, 64, 128, 256, 512 };
+  static const int cls_k[RAMX_CP_NCLASS] = { 16, 16, 16, 8, 4, 2 };
+  const char *fk = getenv("RAMX_CP_K");              // test hook: at most this many lanes per flank
+  const int force = fk ? atoi(fk) : 0;
+  for (int c = 0; c < RAMX_CP_NCLASS; c++)
+  {
+    if (nx > cls_nx[c]) continue;
+    int k = cls_k[c];
+    if (force >= 2 && force < k) k = force;
+    if (cp_cells(W, k) > CP_MAX_CELLS) continue;
+    *K = k;
+    *threads = ((cls_nx[c] * k + 63) / 64) * 64;
+    return c;
+  }
+  return -1;
+}
+
+template <int W, int K>
+static int cp_launch(hipStream_t st, int threads, int F, const CPArgs &a)
+{
+  if (CpCfg<W, K>::C > CP_MAX_CELLS) return RAMX_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL((ramx_cp_family_kernel<W, (CpCfg<W, K>::C > CP_MAX_CELLS ? 16 : K)>), dim3(F), dim3(threads), 0, st, a);
+  return hipGetLastError() == hipSuccess ? RAMX_OK : RAMX_ERR_HIP;
+}
+
+template <int W>
+static int cp_launch_w(hipStream_t st, int K, int threads, int F, const CPArgs &a)
+{
+  switch (K)
+  {
+    case 16: return cp_launch<W, 16>(st, threads, F, a);
+    case 8: return cp_launch<W, 8>(st, threads, F, a);
+    case 4: return cp_launch<W, 4>(st, threads, F, a);
+    case 2: return cp_launch<W, 2>(st, threads, F, a);
+  }
+  return RAMX_ERR_UNSUPPORTED;
+}
+
+int ramx_cp_launch_families(hipStream_t st, int W, int K, int threads, int F, const CPArgs &a)
+{
+  if (F <= 0) return RAMX_OK;
+  if (threads < 64 || threads > 1024 || (threads & 63)) return RAMX_ERR_ARG;
+  switch (W)
+  {
+    case 14: return cp_launch_w<14>(st, K, threads, F, a);
+    case 20: return cp_launch_w<20>(st, K, threads, F, a);
+    case 40: return cp_launch_w<40>(st, K, threads, F, a);
+    case 80: return cp_launch_w<80>(st, K, threads, F, a);
+  }
+  return RAMX_ERR_UNSUPPORTED;
+}

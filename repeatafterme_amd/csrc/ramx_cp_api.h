@@ -1,0 +1,28 @@
+// ramx_cp_api.h -- host-side interface of the cell-parallel kernels (ramx_cp.hip), used by ramx_device.hip.
+// Internal to libramx (not installed).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "ramx_kernels_common.h"
+
+struct CPArgs
+{
+  const unsigned *bases;        // [KW][Np] packed windows (ramx_pack_kernel)
+  const int2 *bounds;
+  const FamDesc *fam;
+  int2 *trim;                   // per flank
+  RamxCtl *ctl_out;             // per family
+  signed char *cons_out;        // [family][L]
+  int2 *state_out;              // optional (tests): final rows, [flank][2W+1] (m, e), else NULL
+  int Np, KW, L, go, ge, cap, minimp, when_to_stop;
+  int tab[RAMX_NCLASS][4];
+};
+
+#define RAMX_CP_NCLASS 6
+// Largest family (flanks) the cell-parallel family kernel takes for this band width and scoring system, 0 if none:
+// non-positive gap penalties (chain-free candidates), int8 scores, every reachable |score| < 2^23 (packed keys).
+int ramx_cp_max_family(int W, int go, int ge, const int (&tab)[RAMX_NCLASS][4], int L);
+// class of a family of nx flanks (0 .. RAMX_CP_NCLASS-1): lanes per flank and workgroup size; -1 if too large
+int ramx_cp_class(int W, int nx, int *lanes_per_flank, int *threads);
+int ramx_cp_launch_families(hipStream_t st, int W, int lanes_per_flank, int threads, int n_families, const CPArgs &a);

@@ -47,6 +47,7 @@
 #include "ramx_kernels_common.h"
 #include "ramx_kernels_stream.h"
 #include "ramx_kernels_resident.h"
+#include "ramx_cp_api.h"
 
 // ------------------------------------------------------------------------------------------
 // error plumbing
@@ -81,6 +82,8 @@ static double now_ms(void)
 // ------------------------------------------------------------------------------------------
 // host side of seam 2
 // ------------------------------------------------------------------------------------------
+#define RAMX_NGROUP (RAMX_CP_NCLASS + 4)   // batch mode: cell-parallel classes, then the four lane-per-flank workgroup shapes
+
 struct ramx_dev
 {
   int ordinal;
@@ -108,8 +111,9 @@ struct ramx_dev
   void *hostbox_map; size_t hostbox_bytes; PeerBox *hostbox_host; int hostbox_registered;
   PeerBox *hostbox_mirror;   // device-memory copy of my host box, kept current by block 0 (the other blocks poll it)
   PeerBox *devbox;     // this rank's fine-grained device-memory box (exported over hipIpc)
-  hipStream_t cls_stream[4]; hipEvent_t cls_ready, cls_done[4]; int cls_init;   // batch mode: one stream per workgroup shape
+  hipStream_t cls_stream[RAMX_NGROUP]; hipEvent_t cls_ready, cls_done[RAMX_NGROUP]; int cls_init;   // batch mode: one stream per workgroup shape
   int force_chain;   // RAMX_FORCE_CHAIN=1: always run the full candidate recurrence (test hook)
+  int2 *d_cpstate; size_t cap_cpstate; int cpstate_W, cpstate_n;   // RAMX_CP_PEEK=1: final rows of the cell-parallel kernel (tests)
 };
 
 extern "C" int ramx_device_count(void)
@@ -169,11 +173,11 @@ extern "C" void ramx_dev_destroy(ramx_dev *d)
   }
   if (d->cls_init)
   {
-    for (int c = 0; c < 4; c++) { (void)hipStreamDestroy(d->cls_stream[c]); (void)hipEventDestroy(d->cls_done[c]); }
+    for (int c = 0; c < RAMX_NGROUP; c++) { (void)hipStreamDestroy(d->cls_stream[c]); (void)hipEventDestroy(d->cls_done[c]); }
     (void)hipEventDestroy(d->cls_ready);
   }
   if (d->devbox) (void)hipFree(d->devbox);
-  (void)hipFree(d->d_fam); (void)hipFree(d->d_famctl);
+  (void)hipFree(d->d_fam); (void)hipFree(d->d_famctl); (void)hipFree(d->d_cpstate);
   if (d->hostbox_mirror) (void)hipFree(d->hostbox_mirror);
   if (d->d_peer) (void)hipFree(d->d_peer);
   for (int i = 0; i < 2; i++) (void)hipEventDestroy(d->ev_chk[i]);
@@ -221,7 +225,7 @@ extern "C" int ramx_dev_begin_direction(ramx_dev *d, const ramx_flank *flanks, i
   const int Nx = n_flanks;
   const int Np = ((Nx + 63) / 64) * 64 > 0 ? ((Nx + 63) / 64) * 64 : 64;
   // t'' = o + r + W + 8 runs over [7, L + 2W + 9]
-  const int KW = (p->L + 2 * W + 2) / 8 + 8;   // + pad word in front, + lookahead words read by the kernel
+  const int KW = (p->L + 2 * W + 2) / 8 + 12;  // + pad word in front, + lookahead words read by the kernels
   d->Nx = Nx; d->Np = Np; d->KW = KW; d->p = *p;
   // class table: tab[class][cand] = matrix[cand][code(class)], reference index order [cons][seq]
   for (int c = 0; c < RAMX_NCLASS; c++)
@@ -637,75 +641,145 @@ extern "C" int ramx_dev_run_families(ramx_dev *d, const ramx_flank *flanks, int3
   if (maxn > 512) { ramx_set_error("batch mode: a family has more than 512 flanks"); return RAMX_ERR_UNSUPPORTED; }
   if (n_families == 0) return RAMX_OK;
   const int Np = n_padded > 0 ? n_padded : 64;
-  const int KW = (L + 2 * W + 2) / 8 + 8;
+  const int KW = (L + 2 * W + 2) / 8 + 12;
   int rc;
   if ((rc = ensure(&d->d_flanks, &d->cap_flanks, (size_t)Np * sizeof(ramx_flank)))) return rc;
   if ((rc = ensure(&d->d_bases, &d->cap_bases, (size_t)KW * Np * sizeof(unsigned)))) return rc;
   if ((rc = ensure(&d->d_bounds, &d->cap_bounds, (size_t)Np * sizeof(int2)))) return rc;   // kept between calls: hipFree/hipMalloc
   if ((rc = ensure(&d->d_trim, &d->cap_trim, (size_t)Np * sizeof(int2)))) return rc;       // per call cost ~0.5 ms of device sync
   if ((rc = ensure(&d->d_cons, &d->cap_cons, (size_t)n_families * (L > 0 ? L : 1) + 16))) return rc;
-  // descriptors grouped by workgroup shape (64, 128, 256, 512 threads = 1, 2, 4, 8 tiles): one launch per non-empty
-  // class, so a 100-flank family occupies two waves, not four
-  FamDesc *hfd = (FamDesc *)malloc(sizeof(FamDesc) * n_families);
-  int cls_first[5] = { 0, 0, 0, 0, 0 }, cls_count[4] = { 0, 0, 0, 0 };
-  auto cls_of = [](int nx) { return nx <= 64 ? 0 : nx <= 128 ? 1 : nx <= 256 ? 2 : 3; };
-  for (int f = 0; f < n_families; f++) cls_count[cls_of(fam_count[f])]++;
-  for (int c = 0; c < 4; c++) cls_first[c + 1] = cls_first[c] + cls_count[c];
+  // Route of every family.  Groups 0 .. RAMX_CP_NCLASS-1: the cell-parallel kernel (K lanes per flank, ramx_cp.hip) for
+  // families it can take -- supported band width and scoring system, small enough for one workgroup at K lanes per
+  // flank, every flank either empty or starting at or before the first base behind the core edge (t_lo <= 0; the
+  // masked band's carry argument needs the out-of-bounds prefix to end at or before the band centre).  Groups
+  // RAMX_CP_NCLASS ..: one lane per flank, by workgroup shape (64, 128, 256, 512 threads = 1, 2, 4, 8 tiles).
+  int tab9[RAMX_NCLASS][4];
+  for (int c = 0; c < RAMX_NCLASS; c++)
   {
-    int fill[4] = { cls_first[0], cls_first[1], cls_first[2], cls_first[3] };
+    const int code = (c == 8) ? RAMX_SYM_N : c;
+    for (int k = 0; k < 4; k++) tab9[c][k] = p->matrix[k * 100 + code];
+  }
+  const int cp_max = d->force_chain ? 0 : ramx_cp_max_family(W, p->gapopen, p->gapextn, tab9, L);
+  FamDesc *hfd = (FamDesc *)malloc(sizeof(FamDesc) * n_families);
+  int *grp = (int *)malloc(sizeof(int) * n_families);
+  int cls_first[RAMX_NGROUP + 1], cls_count[RAMX_NGROUP], cp_k[RAMX_CP_NCLASS], cp_threads[RAMX_CP_NCLASS];
+  memset(cls_count, 0, sizeof(cls_count));
+  memset(cp_k, 0, sizeof(cp_k)); memset(cp_threads, 0, sizeof(cp_threads));
+  auto cls_of = [](int nx) { return nx <= 64 ? 0 : nx <= 128 ? 1 : nx <= 256 ? 2 : 3; };
+  int n_cp = 0;
+  for (int f = 0; f < n_families; f++)
+  {
+    int g = RAMX_CP_NCLASS + cls_of(fam_count[f]);
+    if (fam_count[f] > 0 && fam_count[f] <= cp_max)
+    {
+      bool ok = true;
+      for (int i = 0; i < fam_count[f] && ok; i++)
+      {
+        const ramx_flank &x = flanks[fam_first[f] + i];
+        ok = (x.t_lo <= 0) || (x.t_lo > x.t_hi);
+      }
+      int k = 0, th = 0;
+      const int c = ok ? ramx_cp_class(W, fam_count[f], &k, &th) : -1;
+      if (c >= 0) { g = c; cp_k[c] = k; cp_threads[c] = th; n_cp++; }
+    }
+    grp[f] = g;
+    cls_count[g]++;
+  }
+  cls_first[0] = 0;
+  for (int c = 0; c < RAMX_NGROUP; c++) cls_first[c + 1] = cls_first[c] + cls_count[c];
+  {
+    int fill[RAMX_NGROUP];
+    for (int c = 0; c < RAMX_NGROUP; c++) fill[c] = cls_first[c];
     for (int f = 0; f < n_families; f++)
     {
-      FamDesc &x = hfd[fill[cls_of(fam_count[f])]++];
+      FamDesc &x = hfd[fill[grp[f]]++];
       x.tile0 = fam_first[f] / 64; x.ntiles = (fam_count[f] + 63) / 64; x.nx = fam_count[f]; x.id = f;
     }
   }
-  if ((rc = ensure(&d->d_fam, &d->cap_fam, sizeof(FamDesc) * (size_t)n_families))) { free(hfd); return rc; }
-  if ((rc = ensure(&d->d_famctl, &d->cap_famctl, sizeof(RamxCtl) * (size_t)n_families))) { free(hfd); return rc; }
-  FamDesc *dfd = (FamDesc *)d->d_fam; RamxCtl *dctl = d->d_famctl;
-  HIPCHK(hipMemcpyAsync(dfd, hfd, sizeof(FamDesc) * n_families, hipMemcpyHostToDevice, d->stream));
-  if (n_padded) HIPCHK(hipMemcpyAsync(d->d_flanks, flanks, (size_t)n_padded * sizeof(ramx_flank), hipMemcpyHostToDevice, d->stream));
-  dim3 grid((Np + 255) / 256, KW);
-  hipLaunchKernelGGL(ramx_pack_kernel, grid, dim3(256), 0, d->stream, d->d_lib, (unsigned long long)d->lib_len, d->d_flanks,
-                     n_padded, Np, W, d->d_bases, d->d_bounds);
-  HIPCHK(hipGetLastError());
+  // from here on every failure leaves through `done` (host buffers are released there)
+  RamxCtl *hctl = NULL;
+  int2 *tmp = NULL;
+  float ms = 0;
+#define FAMCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
+    ramx_set_error("HIP error %s at %s:%d (%s)", hipGetErrorString(e_), __FILE__, __LINE__, #call); rc = RAMX_ERR_HIP; goto done; } } while (0)
+  FamDesc *dfd; RamxCtl *dctl;
   FArgs fa;
+  const bool legacy_any = n_cp < n_families;
+  if ((rc = ensure(&d->d_fam, &d->cap_fam, sizeof(FamDesc) * (size_t)n_families))) goto done;
+  if ((rc = ensure(&d->d_famctl, &d->cap_famctl, sizeof(RamxCtl) * (size_t)n_families))) goto done;
+  dfd = (FamDesc *)d->d_fam; dctl = d->d_famctl;
+  FAMCHK(hipMemcpyAsync(dfd, hfd, sizeof(FamDesc) * n_families, hipMemcpyHostToDevice, d->stream));
+  if (n_padded) FAMCHK(hipMemcpyAsync(d->d_flanks, flanks, (size_t)n_padded * sizeof(ramx_flank), hipMemcpyHostToDevice, d->stream));
+  hipLaunchKernelGGL(ramx_pack_kernel, dim3((Np + 255) / 256, KW), dim3(256), 0, d->stream, d->d_lib, (unsigned long long)d->lib_len,
+                     d->d_flanks, n_padded, Np, W, d->d_bases, d->d_bounds);
+  FAMCHK(hipGetLastError());
   memset(&fa, 0, sizeof(fa));
   fa.bases = d->d_bases; fa.bounds = d->d_bounds; fa.fam = dfd; fa.trim = d->d_trim; fa.ctl_out = dctl; fa.cons_out = d->d_cons;
   fa.Np = Np; fa.L = L; fa.go = p->gapopen; fa.ge = p->gapextn; fa.cap = p->cappenalty; fa.minimp = p->minimprovement;
   fa.when_to_stop = p->when_to_stop;
-  for (int c = 0; c < RAMX_NCLASS; c++)
-  {
-    const int code = (c == 8) ? RAMX_SYM_N : c;
-    for (int k = 0; k < 4; k++) fa.tab[c][k] = p->matrix[k * 100 + code];
-  }
+  memcpy(fa.tab, tab9, sizeof(fa.tab));
   fa.pack_ok = getenv("RAMX_NO_FASTPACK") ? 0 : fast_pack_ok(fa.tab, fa.go, fa.ge, L, W);
   if (fa.pack_ok && getenv("RAMX_NO_MASKHI") == NULL) fa.pack_ok = 2;
 #ifdef RAMX_PRK_TIMING
-  HIPCHK(hipMalloc((void **)&fa.dbg, 8 * 8 * sizeof(unsigned long long)));
-  HIPCHK(hipMemset(fa.dbg, 0, 8 * 8 * sizeof(unsigned long long)));
+  FAMCHK(hipMalloc((void **)&fa.dbg, 8 * 8 * sizeof(unsigned long long)));
+  FAMCHK(hipMemset(fa.dbg, 0, 8 * 8 * sizeof(unsigned long long)));
 #endif
-  HIPCHK(hipEventRecord(d->ev_begin, d->stream));
-  // the shapes run side by side: one stream per class, forked from / joined into the library's stream
+  FAMCHK(hipEventRecord(d->ev_begin, d->stream));
+  // the groups run side by side: one stream per group, forked from / joined into the library's stream
   if (!d->cls_init)
   {
-    for (int c = 0; c < 4; c++) { HIPCHK(hipStreamCreateWithFlags(&d->cls_stream[c], hipStreamNonBlocking)); HIPCHK(hipEventCreateWithFlags(&d->cls_done[c], hipEventDisableTiming)); }
-    HIPCHK(hipEventCreateWithFlags(&d->cls_ready, hipEventDisableTiming));
+    for (int c = 0; c < RAMX_NGROUP; c++)
+    {
+      FAMCHK(hipStreamCreateWithFlags(&d->cls_stream[c], hipStreamNonBlocking));
+      FAMCHK(hipEventCreateWithFlags(&d->cls_done[c], hipEventDisableTiming));
+    }
+    FAMCHK(hipEventCreateWithFlags(&d->cls_ready, hipEventDisableTiming));
     d->cls_init = 1;
   }
-  HIPCHK(hipEventRecord(d->cls_ready, d->stream));
-  // every class stream waits (the register-resident branch below merges classes AFTER this point: a stream that is
+  FAMCHK(hipEventRecord(d->cls_ready, d->stream));
+  // every group stream waits (the register-resident branch below merges shapes AFTER this point: a stream that is
   // launched on must never have skipped the wait -- uploads and the pack kernel run on the library's stream)
-  for (int c = 0; c < 4; c++) HIPCHK(hipStreamWaitEvent(d->cls_stream[c], d->cls_ready, 0));
-  if (!resident)
+  for (int c = 0; c < RAMX_NGROUP; c++) FAMCHK(hipStreamWaitEvent(d->cls_stream[c], d->cls_ready, 0));
+  // ---- cell-parallel groups ------------------------------------------------------------------
+  if (n_cp > 0)
+  {
+    CPArgs ca;
+    memset(&ca, 0, sizeof(ca));
+    ca.bases = d->d_bases; ca.bounds = d->d_bounds; ca.trim = d->d_trim; ca.ctl_out = dctl; ca.cons_out = d->d_cons;
+    ca.state_out = NULL;
+    ca.Np = Np; ca.KW = KW; ca.L = L; ca.go = p->gapopen; ca.ge = p->gapextn; ca.cap = p->cappenalty; ca.minimp = p->minimprovement;
+    ca.when_to_stop = p->when_to_stop;
+    memcpy(ca.tab, tab9, sizeof(ca.tab));
+    if (getenv("RAMX_CP_PEEK") != NULL)
+    {
+      // test hook: keep the final rows of every flank, [flank][2W+1] (m, e), for ramx_dev_peek_family_state
+      const size_t need = (size_t)Np * (2 * W + 1) * sizeof(int2);
+      if ((rc = ensure(&d->d_cpstate, &d->cap_cpstate, need))) goto done;
+      FAMCHK(hipMemsetAsync(d->d_cpstate, 0, need, d->stream));
+      FAMCHK(hipEventRecord(d->cls_ready, d->stream));
+      for (int c = 0; c < RAMX_CP_NCLASS; c++) FAMCHK(hipStreamWaitEvent(d->cls_stream[c], d->cls_ready, 0));
+      ca.state_out = (int2 *)d->d_cpstate;
+      d->cpstate_W = W; d->cpstate_n = Np;
+    }
+    for (int c = 0; c < RAMX_CP_NCLASS; c++)
+    {
+      if (cls_count[c] == 0) continue;
+      ca.fam = dfd + cls_first[c];
+      rc = ramx_cp_launch_families(d->cls_stream[c], W, cp_k[c], cp_threads[c], cls_count[c], ca);
+      if (rc != RAMX_OK) { ramx_set_error("cell-parallel family kernel launch failed (W %d, %d lanes per flank)", W, cp_k[c]); goto done; }
+    }
+  }
+  // ---- one lane per flank ---------------------------------------------------------------------
+  if (legacy_any && !resident)
   {
     // rows of every family in the (in-place) row buffer: 16 B x (W + 1) slots per flank
     const size_t state_bytes = (size_t)Np * (W + 1) * sizeof(int4);
     if (state_bytes > d->cap_state || !d->d_state[0])
     {
-      if (d->d_state[0]) HIPCHK(hipFree(d->d_state[0]));
-      if (d->d_state[1] && d->d_state[1] != d->d_state[0]) HIPCHK(hipFree(d->d_state[1]));
-      d->d_state[0] = d->d_state[1] = NULL;
-      HIPCHK(hipMalloc((void **)&d->d_state[0], state_bytes));
+      if (d->d_state[0]) FAMCHK(hipFree(d->d_state[0]));
+      if (d->d_state[1] && d->d_state[1] != d->d_state[0]) FAMCHK(hipFree(d->d_state[1]));
+      d->d_state[0] = d->d_state[1] = NULL; d->cap_state = 0;
+      FAMCHK(hipMalloc((void **)&d->d_state[0], state_bytes));
       d->d_state[1] = d->d_state[0];
       d->cap_state = state_bytes;
     }
@@ -717,61 +791,63 @@ extern "C" int ramx_dev_run_families(ramx_dev *d, const ramx_flank *flanks, int3
     memcpy(fs.k.tab, fa.tab, sizeof(fs.k.tab));
     fs.fam = dfd; fs.ctl_out = dctl; fs.cons_out = d->d_cons; fs.L = L;
     const bool chain = p->gapopen > 0 || p->gapextn > 0 || d->force_chain;
-#define RAMX_FS_LAUNCH(CH, BL, C) do { if (cls_count[C] > 0) { fs.fam = dfd + cls_first[C]; \
-      hipLaunchKernelGGL((ramx_family_stream_kernel<CH, BL>), dim3(cls_count[C]), dim3(BL), 0, d->cls_stream[C], fs); } } while (0)
+#define RAMX_FS_LAUNCH(CH, BL, C) do { const int g_ = RAMX_CP_NCLASS + (C); if (cls_count[g_] > 0) { fs.fam = dfd + cls_first[g_]; \
+      hipLaunchKernelGGL((ramx_family_stream_kernel<CH, BL>), dim3(cls_count[g_]), dim3(BL), 0, d->cls_stream[g_], fs); } } while (0)
     if (chain) { RAMX_FS_LAUNCH(true, 64, 0); RAMX_FS_LAUNCH(true, 128, 1); RAMX_FS_LAUNCH(true, 256, 2); RAMX_FS_LAUNCH(true, 512, 3); }
     else { RAMX_FS_LAUNCH(false, 64, 0); RAMX_FS_LAUNCH(false, 128, 1); RAMX_FS_LAUNCH(false, 256, 2); RAMX_FS_LAUNCH(false, 512, 3); }
 #undef RAMX_FS_LAUNCH
-    hipError_t le = hipGetLastError();
-    if (le != hipSuccess) { free(hfd); ramx_set_error("family stream kernel launch: %s", hipGetErrorString(le)); return RAMX_ERR_HIP; }
-    rc = RAMX_OK;
+    FAMCHK(hipGetLastError());
   }
-  else
+  else if (legacy_any)
   {
     // the register-resident kernel gains nothing from smaller workgroups (measured: 11.5 vs 10.3 ms; rotating the live
-    // waves over the SIMDs by arrival order on the CU did not help either): 256 threads up to 256 flanks, in class order
-    cls_count[2] += cls_count[0] + cls_count[1]; cls_first[2] = 0; cls_count[0] = cls_count[1] = 0;
-    rc = RAMX_OK;
-    for (int c = 0; c < 4 && rc == RAMX_OK; c++)
+    // waves over the SIMDs by arrival order on the CU did not help either): 256 threads up to 256 flanks (the three
+    // smaller shapes are adjacent in the descriptor array), 512 above
+    const int g0 = RAMX_CP_NCLASS;
+    const int n256 = cls_count[g0] + cls_count[g0 + 1] + cls_count[g0 + 2], n512 = cls_count[g0 + 3];
+    if (n256 > 0)
     {
-      if (cls_count[c] == 0) continue;
-      fa.fam = dfd + cls_first[c];
-      const int n = cls_count[c];
-      hipStream_t st = d->cls_stream[c];
-      if (c <= 2) rc = (W == 14) ? fam_launch<14, 256>(d, fa, n, st) : (W == 20) ? fam_launch<20, 256>(d, fa, n, st) : fam_launch<40, 256>(d, fa, n, st);
-      else             rc = (W == 14) ? fam_launch<14, 512>(d, fa, n, st) : (W == 20) ? fam_launch<20, 512>(d, fa, n, st) : fam_launch<40, 512>(d, fa, n, st);
+      fa.fam = dfd + cls_first[g0];
+      hipStream_t st = d->cls_stream[g0 + 2];
+      rc = (W == 14) ? fam_launch<14, 256>(d, fa, n256, st) : (W == 20) ? fam_launch<20, 256>(d, fa, n256, st) : fam_launch<40, 256>(d, fa, n256, st);
+      if (rc != RAMX_OK) goto done;
+      cls_count[g0 + 2] = n256; cls_count[g0] = cls_count[g0 + 1] = 0;     // for the join below
+    }
+    if (n512 > 0)
+    {
+      fa.fam = dfd + cls_first[g0 + 3];
+      hipStream_t st = d->cls_stream[g0 + 3];
+      rc = (W == 14) ? fam_launch<14, 512>(d, fa, n512, st) : (W == 20) ? fam_launch<20, 512>(d, fa, n512, st) : fam_launch<40, 512>(d, fa, n512, st);
+      if (rc != RAMX_OK) goto done;
     }
   }
-  if (rc != RAMX_OK) { free(hfd); return rc; }
-  for (int c = 0; c < 4; c++)
-    if (cls_count[c] > 0) { HIPCHK(hipEventRecord(d->cls_done[c], d->cls_stream[c])); HIPCHK(hipStreamWaitEvent(d->stream, d->cls_done[c], 0)); }
-  HIPCHK(hipEventRecord(d->ev_end, d->stream));
-  HIPCHK(hipStreamSynchronize(d->stream));
-  float ms = 0;
-  HIPCHK(hipEventElapsedTime(&ms, d->ev_begin, d->ev_end));
+  for (int c = 0; c < RAMX_NGROUP; c++)
+    if (cls_count[c] > 0) { FAMCHK(hipEventRecord(d->cls_done[c], d->cls_stream[c])); FAMCHK(hipStreamWaitEvent(d->stream, d->cls_done[c], 0)); }
+  FAMCHK(hipEventRecord(d->ev_end, d->stream));
+  FAMCHK(hipStreamSynchronize(d->stream));
+  FAMCHK(hipEventElapsedTime(&ms, d->ev_begin, d->ev_end));
 #ifdef RAMX_PRK_TIMING
-  if (resident)
+  if (resident && legacy_any)
   {
     unsigned long long h[64];
-    HIPCHK(hipMemcpy(h, fa.dbg, sizeof(h), hipMemcpyDeviceToHost));
+    FAMCHK(hipMemcpy(h, fa.dbg, sizeof(h), hipMemcpyDeviceToHost));
     static const char *nm[6] = { "vote + stop rule", "winner table+barrier", "band + contrib", "wave reduce", "end barrier", "loop top" };
     const double cols = h[6] ? (double)h[6] : 1.0;
     fprintf(stderr, "FAM_TIMING family 0 (block 0), %.0f columns, ns per column per wave:\n", cols);
     for (int k = 0; k < 6; k++)
       fprintf(stderr, "FAM_TIMING %-22s w0 %7.1f  w1 %7.1f  w2 %7.1f  w3 %7.1f\n", nm[k], 10.0 * h[k] / cols, 10.0 * h[8 + k] / cols,
               10.0 * h[16 + k] / cols, 10.0 * h[24 + k] / cols);
-    (void)hipFree(fa.dbg);
   }
+  if (fa.dbg) (void)hipFree(fa.dbg);
 #endif
-  RamxCtl *hctl = (RamxCtl *)malloc(sizeof(RamxCtl) * n_families);
-  HIPCHK(hipMemcpy(hctl, dctl, sizeof(RamxCtl) * n_families, hipMemcpyDeviceToHost));
-  if (cons && L > 0) HIPCHK(hipMemcpy(cons, d->d_cons, (size_t)n_families * L, hipMemcpyDeviceToHost));
+  hctl = (RamxCtl *)malloc(sizeof(RamxCtl) * n_families);
+  FAMCHK(hipMemcpy(hctl, dctl, sizeof(RamxCtl) * n_families, hipMemcpyDeviceToHost));
+  if (cons && L > 0) FAMCHK(hipMemcpy(cons, d->d_cons, (size_t)n_families * L, hipMemcpyDeviceToHost));
   if ((trim_high || trim_pos) && n_padded)
   {
-    int2 *tmp = (int2 *)malloc((size_t)n_padded * sizeof(int2));
-    HIPCHK(hipMemcpy(tmp, d->d_trim, (size_t)n_padded * sizeof(int2), hipMemcpyDeviceToHost));
+    tmp = (int2 *)malloc((size_t)n_padded * sizeof(int2));
+    FAMCHK(hipMemcpy(tmp, d->d_trim, (size_t)n_padded * sizeof(int2), hipMemcpyDeviceToHost));
     for (int i = 0; i < n_padded; i++) { if (trim_high) trim_high[i] = tmp[i].x; if (trim_pos) trim_pos[i] = tmp[i].y; }
-    free(tmp);
   }
   for (int f = 0; f < n_families && infos; f++)
   {
@@ -783,11 +859,16 @@ extern "C" int ramx_dev_run_families(ramx_dev *d, const ramx_flank *flanks, int3
     infos[f].n_extendable = fam_count[f];
     infos[f].launches = 1;
     infos[f].loop_ms = ms;
-    infos[f].persistent = resident ? 1 : 2;     /* 2: streaming family kernel */
+    /* 1: rows resident in registers (3: of K lanes per flank, the cell-parallel kernel); 2: streaming family kernel */
+    infos[f].persistent = grp[f] < RAMX_CP_NCLASS ? 1 : (resident ? 1 : 2);
+    infos[f].lanes_per_flank = grp[f] < RAMX_CP_NCLASS ? cp_k[grp[f]] : 1;
   }
-  free(hctl); free(hfd);
+  rc = RAMX_OK;
+done:
+#undef FAMCHK
+  free(hctl); free(tmp); free(hfd); free(grp);
   d->ready = 0;       // the single-family buffers were reused: begin_direction must be called again before run_direction
-  return RAMX_OK;
+  return rc;
 }
 
 extern "C" int ramx_dev_run_direction(ramx_dev *d, ramx_run_info *info)
@@ -956,6 +1037,17 @@ extern "C" int ramx_dev_peek_state(ramx_dev *d, int32_t flank, int32_t *cells, i
     if (2 * q + 1 < B) { cells[4 * q + 2] = v.z; cells[4 * q + 3] = v.w; }
     else { if (high) *high = v.z; if (pos) *pos = v.w; }
   }
+  return RAMX_OK;
+}
+
+extern "C" int ramx_dev_peek_family_state(ramx_dev *d, int32_t flank, int32_t *cells)
+{
+  if (!d) d = ramx_default_device();      // seam 1 runs on the process-wide session
+  if (!d || !d->d_cpstate || flank < 0 || flank >= d->cpstate_n || !cells)
+  { ramx_set_error("ramx_dev_peek_family_state: nothing kept (set RAMX_CP_PEEK=1 before the batch call)"); return RAMX_ERR_ARG; }
+  HIPCHK(hipSetDevice(d->ordinal));
+  const int B = 2 * d->cpstate_W + 1;
+  HIPCHK(hipMemcpy(cells, d->d_cpstate + (size_t)flank * B, (size_t)B * sizeof(int2), hipMemcpyDeviceToHost));
   return RAMX_OK;
 }
 

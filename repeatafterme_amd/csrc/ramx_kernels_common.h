@@ -46,6 +46,7 @@ struct FamDesc { int tile0, ntiles, nx, id; };      // first 64-flank tile, tile
 // ------------------------------------------------------------------------------------------
 // pack kernel: 1-byte library -> transposed, pre-oriented 4-bit windows
 // ------------------------------------------------------------------------------------------
+#ifndef RAMX_SECONDARY_TU
 __global__ void ramx_pack_kernel(const signed char *__restrict__ lib, unsigned long long lib_len,
                                  const ramx_flank *__restrict__ fl, int Nx, int Np, int W,
                                  unsigned *__restrict__ bases, int2 *__restrict__ bounds)
@@ -81,6 +82,7 @@ __global__ void ramx_pack_kernel(const signed char *__restrict__ lib, unsigned l
     bounds[n] = make_int2(1, 0);   // empty interval: every cell out of bounds
   bases[(size_t)k * Np + n] = word;
 }
+#endif
 
 // ------------------------------------------------------------------------------------------
 // column kernel

@@ -1,0 +1,450 @@
+// ramx_kernels_cp.h -- the CELL-PARALLEL band: K lanes of a wavefront share one flanking sequence
+// (device code of libramx; included by ramx_cp.hip only)
+//
+// compute_nw_row (bnw_extend.c:750-1048) walks the 2W+1 cells of a band row in order because the insertion term of
+// cell j reads cell j-1 of the SAME row (:972-985).  In the transformed state (m, e) of ramx_kernels_common.h that
+// dependency is   e_j = max(x_j, e_{j-1}) + ge,  x_j = max(sub_j + go, del_j)   -- a max-plus prefix scan
+// (G[j] = max(c[j], G[j-1] + ge) with resets at out-of-bounds cells).  Here a row is split into
+// K blocks of C = ceil((2W+1)/K) consecutive cells, one block per lane (K = 2, 4, 8 or 16 lanes: one DPP row holds
+// 16/K flanks, a wavefront 64/K):
+//
+//   pass 1   every lane runs the serial recurrence over its own C cells with no carry-in (5 VALU per cell);
+//   scan     the block totals A_l, tilted by l*C*ge, go through a DPP prefix-max inside the K-lane group
+//            (row_shr / quad_perm, no LDS), giving every lane the exact e of the cell left of its block;
+//   fix-up   m_i = max(m_i, carry + i*ge), e_i = max(e_i, carry + (i+1)*ge)   (3 VALU per cell);
+//   reduce   best cell of the row (packed (score, 255 - cell) keys) and the four chain-free candidate maxima of
+//            row r+1 (see ramx_kernels_common.h) by a DPP butterfly over the group.
+//
+// All of it is integer max/add on values that never overflow, so re-association is exact: the stored cells equal the
+// serial reference's bit for bit (tests/test_gpu_cp.py compares the per-cell state with the oracle).  A column costs
+// ~20 VALU per cell / K lanes instead of 16.5 per cell in one lane: a 100-flank family runs on 13 waves instead of 2.
+//
+// Cells j >= 2W+1 of the last blocks ("dead" cells) and whole dead lanes exist because K*C > 2W+1.  On the masked
+// path they are ordinary out-of-bounds cells (sentinel fill).  On the in-bounds fast path they run free on very
+// negative values; four selects per row keep every live value out of them (the insertion chain and the carry are cut
+// at cell 2W+1) and the deletion term of cell 2W is forced to the reference's "impossible" value (bnw_extend.c:892).
+#pragma once
+
+#include "ramx_kernels_resident.h"
+#include "ramx_cp_api.h"
+
+#define CP_IDN (-1500000000)      // identity of the max scans: below every value a live cell can hold, far from INT_MIN
+#define CP_IMIN (-2147483647 - 1)
+
+#define CP_QP(a, b, c, d) "quad_perm:[" #a "," #b "," #c "," #d "]"
+
+// dst = max(dst, dpp(dst)): lanes whose DPP source is invalid (row boundary, bound_ctrl:0) or masked keep dst.
+// A DPP read needs two wait states after the VALU write of its source (s_nop 1 in front; steps on different
+// registers are interleaved where several values are reduced so that only the first step pays it).
+#define CP_MAX1(v, ctrl, masks) asm("s_nop 1\n\tv_max_i32_dpp %0, %0, %0 " ctrl " " masks : "+v"(v))
+#define CP_FULL "row_mask:0xf bank_mask:0xf"
+
+template <int K>
+__device__ __forceinline__ int cp_scan_max(int v)   // inclusive prefix max over the K-lane group (identity: keep own)
+{
+  if (K == 16)
+  {
+    CP_MAX1(v, "row_shr:1", CP_FULL); CP_MAX1(v, "row_shr:2", CP_FULL); CP_MAX1(v, "row_shr:4", CP_FULL); CP_MAX1(v, "row_shr:8", CP_FULL);
+  }
+  else if (K == 2) CP_MAX1(v, CP_QP(0, 0, 2, 2), CP_FULL);
+  else
+  {
+    CP_MAX1(v, CP_QP(0, 0, 1, 2), CP_FULL);         // within quads: shift by one (lane 0 of a quad takes itself)
+    CP_MAX1(v, CP_QP(0, 1, 0, 1), CP_FULL);         // shift by two
+    if (K == 8)
+    {
+      int t = v;
+      asm("s_nop 1\n\tv_mov_b32_dpp %0, %0 " CP_QP(3, 3, 3, 3) " " CP_FULL : "+v"(t));     // quad totals
+      asm("s_nop 1\n\tv_max_i32_dpp %0, %1, %0 row_shr:4 row_mask:0xf bank_mask:0xa" : "+v"(v) : "v"(t));   // quads 1, 3 take quad 0, 2
+    }
+  }
+  return v;
+}
+
+// five values at once over the group (butterfly: every lane ends with the maximum)
+template <int K>
+__device__ __forceinline__ void cp_allmax5(int &a, int &b, int &c, int &d, int &e)
+{
+#define CP_STEP5(ctrl) asm("s_nop 1\n\tv_max_i32_dpp %0, %0, %0 " ctrl " " CP_FULL "\n\tv_max_i32_dpp %1, %1, %1 " ctrl " " CP_FULL \
+                           "\n\tv_max_i32_dpp %2, %2, %2 " ctrl " " CP_FULL "\n\tv_max_i32_dpp %3, %3, %3 " ctrl " " CP_FULL  \
+                           "\n\tv_max_i32_dpp %4, %4, %4 " ctrl " " CP_FULL : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e))
+  if (K >= 2) CP_STEP5(CP_QP(1, 0, 3, 2));
+  if (K >= 4) CP_STEP5(CP_QP(2, 3, 0, 1));
+  if (K >= 8) CP_STEP5("row_half_mirror");
+  if (K >= 16) CP_STEP5("row_mirror");
+#undef CP_STEP5
+}
+
+// Sum over the flanks of a wave of four values that are replicated inside every K-lane group, each < 2^23 (the key
+// bound of cp_supported), 64/K groups: fits 32 bits.  Returns wave-uniform totals.
+template <int K>
+__device__ __forceinline__ void cp_flank_sum4(unsigned (&v)[4])
+{
+#define CP_ADD4(ctrl, masks) asm("s_nop 1\n\tv_add_u32_dpp %0, %0, %0 " ctrl " " masks "\n\tv_add_u32_dpp %1, %1, %1 " ctrl " " masks \
+                                 "\n\tv_add_u32_dpp %2, %2, %2 " ctrl " " masks "\n\tv_add_u32_dpp %3, %3, %3 " ctrl " " masks    \
+                                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]))
+  if (K <= 2) CP_ADD4("row_ror:2", CP_FULL);
+  if (K <= 4) CP_ADD4("row_ror:4", CP_FULL);
+  if (K <= 8) CP_ADD4("row_ror:8", CP_FULL);        // every lane: total of its row of 16
+  CP_ADD4("row_bcast:15", "row_mask:0xa bank_mask:0xf");
+  CP_ADD4("row_bcast:31", "row_mask:0xc bank_mask:0xf");
+#undef CP_ADD4
+#pragma unroll
+  for (int k = 0; k < 4; k++) v[k] = (unsigned)__builtin_amdgcn_readlane((int)v[k], 63);
+}
+
+template <int W, int K>
+struct CpCfg
+{
+  static constexpr int B = 2 * W + 1;
+  static constexpr int C = (B + K - 1) / K;          // cells per lane
+  static constexpr int LB = (B - 1) / C;             // lane holding cell B-1
+  static constexpr int IB = (B - 1) % C;             // its index there
+  static constexpr int NA = (C + 1 + 7) / 8;         // aligned 8-nibble windows covering the C+1 lookups of a row
+  static constexpr int NWL = (C + 7) / 8 + 1;        // base words spanned by nibbles s .. s+C
+};
+
+// per-lane constants of the cell-parallel band
+struct CpLane
+{
+  int l;                 // lane inside the group: owns cells l*C .. l*C + C-1
+  int j0;                // l*C
+  int lCge, lm1Cge;      // l*C*ge, (l-1)*C*ge: tilt of the block totals
+  bool pL0, pLast;       // l == 0, l == K-1
+  bool pFull, pPart, pDead;   // l < LB, l == LB, l > LB
+  int keyfix;            // 255 - j0 - (C-1): turns a block-local key into a band-global one
+  // per row (masked path)
+  int ilo, ihi;          // cell i of this lane is in bounds iff ilo <= i <= ihi (dead cells excluded)
+  int iclo, ichi;        // candidate cell i (row r+1) is in bounds iff iclo <= i <= ichi
+  int iW;                // cells i < iW have band index j < W (edge fill in the first W rows)
+};
+
+// Row r from row r-1 (bnw_extend.c:750-1048), cells split over the group.  G: masked (general) path.
+template <int W, int K, bool G>
+__device__ __forceinline__ void cp_update(const CpLane &ln, const int go, const int ge, const int sh8, const int edgeFx,
+                                          const int (&T)[CpCfg<W, K>::C + 1], int (&m)[CpCfg<W, K>::C], int (&e)[CpCfg<W, K>::C])
+{
+  typedef CpCfg<W, K> Cfg;
+  constexpr int C = Cfg::C, IB = Cfg::IB;
+  // previous row's e of the cell right of this block: the deletion term of the block's last cell
+  int peNext = e[0];
+  asm("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_shl:1 " CP_FULL : "=v"(peNext) : "v"(e[0]), "0"(NEG));   // lane 15 of a row keeps NEG
+  if (K < 16) peNext = ln.pLast ? NEG : peNext;
+  int eprev = ln.pL0 ? NEG : CP_IDN;                 // bnw_extend.c:802-804: no insertion into cell 0
+  // compile-time cell indices (static_for, not the loop unroller: an array indexed by a loop variable is turned into
+  // one wide vector register by the alloca promotion that runs before unrolling, and every branch then copies it whole)
+  static_for([&](auto ic) __attribute__((always_inline))
+  {
+    constexpr int i = decltype(ic)::value;
+    const int sF = __builtin_amdgcn_sbfe(T[i], sh8, 8);          // M[besta][base]: byte `besta` of the packed scores
+    const int sub = m[i] + sF;                                   // :950-956
+    int del = peNext;                                            // :892-905
+    if constexpr (i + 1 < C) del = e[i + 1];
+    if constexpr (i == IB) del = ln.pPart ? NEG : del;           // cell 2W has no deletion predecessor
+    if constexpr (!G && i == IB + 1) eprev = ln.pPart ? CP_IDN : eprev;   // cut the chain into the dead cells
+    const int mN = vmax3(sub, del, eprev);                       // :1007-1018
+    int eN = vmax3(sub + go, del, eprev) + ge;
+    if (G)
+    {
+      const bool inb = (i >= ln.ilo) && (i <= ln.ihi);
+      const int vF = (i < ln.iW) ? edgeFx : SENT;                // :990-1002
+      eN = inb ? eN : vF + ge;                                   // an out-of-bounds cell restarts the chain
+    }
+    m[i] = mN; e[i] = eN; eprev = eN;
+  }, std::make_integer_sequence<int, C>{});
+  // carry: e of the cell left of the block = max over the lanes to the left of (their total decayed by ge per cell)
+  int t = eprev - ln.lCge;
+  t = cp_scan_max<K>(t);
+  int carry = CP_IDN;
+  asm("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_shr:1 " CP_FULL : "=v"(carry) : "v"(t), "0"(CP_IDN));
+  if (K < 16) carry = ln.pL0 ? CP_IDN : carry;
+  carry += ln.lm1Cge;
+  if (!G) carry = ln.pDead ? CP_IDN : carry;
+  int c = carry;
+  static_for([&](auto ic) __attribute__((always_inline))
+  {
+    constexpr int i = decltype(ic)::value;
+    if constexpr (!G && i == IB + 1) c = ln.pPart ? CP_IDN : c;
+    int mi = imax(m[i], c);
+    c += ge;
+    int ei = imax(e[i], c);
+    if (G)
+    {
+      const bool inb = (i >= ln.ilo) && (i <= ln.ihi);
+      const int vF = (i < ln.iW) ? edgeFx : SENT;
+      mi = inb ? mi : vF;
+      ei = inb ? ei : vF + ge;
+    }
+    m[i] = mi; e[i] = ei;
+  }, std::make_integer_sequence<int, C>{});
+}
+
+// Best cell of row r (value, lowest cell on ties: bnw_extend.c:1020-1024) and the best cells of the four candidate rows
+// r+1 (chain-free rule of ramx_kernels_common.h), reduced over the group: every lane returns the same values.
+template <int W, int K, bool G>
+__device__ __forceinline__ void cp_reduce(const CpLane &ln, const int (&T)[CpCfg<W, K>::C + 1], const int (&m)[CpCfg<W, K>::C],
+                                          const int (&e)[CpCfg<W, K>::C], int &bestF, int &jbest, int (&bestA)[4])
+{
+  typedef CpCfg<W, K> Cfg;
+  constexpr int C = Cfg::C, IB = Cfg::IB;
+  int kb = CP_IMIN, kp = CP_IMIN, mE = CP_IDN, eP = CP_IDN;
+  int bA[4] = { CP_IDN, CP_IDN, CP_IDN, CP_IDN }, pend[4] = { CP_IDN, CP_IDN, CP_IDN, CP_IDN };
+  static_for([&](auto ic) __attribute__((always_inline))
+  {
+    constexpr int i = decltype(ic)::value;
+    int key = (int)(((unsigned)m[i] << 8) | (unsigned)(C - 1 - i));
+    if (G) key = ((i >= ln.ilo) && (i <= ln.ihi)) ? key : CP_IMIN;
+    else if constexpr (i > IB) key = ln.pFull ? key : CP_IMIN;
+    int ms = m[i];
+    if (G) ms = ((i >= ln.iclo) && (i <= ln.ichi)) ? ms : SENT;
+    const int t4[4] = { add_sext_byte<0>(ms, T[i + 1]), add_sext_byte<1>(ms, T[i + 1]), add_sext_byte<2>(ms, T[i + 1]),
+                        add_sext_byte<3>(ms, T[i + 1]) };
+    int ev = e[i];
+    if constexpr (i == 0) ev = ln.pL0 ? CP_IDN : ev;             // e of cell 0 is nobody's deletion term
+    if constexpr ((i & 1) == 0 && i + 1 < C)
+    {
+      kp = key; eP = ev;
+#pragma unroll
+      for (int a = 0; a < 4; a++) pend[a] = t4[a];
+    }
+    else if constexpr ((i & 1) != 0)
+    {
+      kb = imax3(kb, kp, key); mE = imax3(mE, eP, ev);
+#pragma unroll
+      for (int a = 0; a < 4; a++) bA[a] = imax3(bA[a], pend[a], t4[a]);
+    }
+    else
+    {
+      kb = imax(kb, key); mE = imax(mE, ev);
+#pragma unroll
+      for (int a = 0; a < 4; a++) bA[a] = imax(bA[a], t4[a]);
+    }
+  }, std::make_integer_sequence<int, C>{});
+  if (!G) kb = ln.pDead ? CP_IMIN : kb;
+  kb += ln.keyfix;                                               // low byte: 255 - j of the block's best cell
+  int r0 = imax(bA[0], mE), r1 = imax(bA[1], mE), r2 = imax(bA[2], mE), r3 = imax(bA[3], mE);
+  cp_allmax5<K>(r0, r1, r2, r3, kb);
+  bestA[0] = r0; bestA[1] = r1; bestA[2] = r2; bestA[3] = r3;
+  bestF = kb >> 8;
+  jbest = 255 - (kb & 255);
+}
+
+// ------------------------------------------------------------------------------------------
+// one workgroup = one family, K lanes per flank
+// ------------------------------------------------------------------------------------------
+template <int W, int K>
+__global__ __launch_bounds__(1024) void ramx_cp_family_kernel(const CPArgs a)
+{
+  typedef CpCfg<W, K> Cfg;
+  constexpr int B = Cfg::B, C = Cfg::C, NA = Cfg::NA, NWL = Cfg::NWL, FPW = 64 / K;
+  static_assert(K == 2 || K == 4 || K == 8 || K == 16, "lanes per flank");
+  static_assert(B <= 255, "cell index must fit the key's low byte");
+  struct Smem
+  {
+    int tab[16];                                     // class -> {M[A][b] | M[C][b] | M[G][b] | M[T][b]} as four int8
+    unsigned long long vote[3][4];
+  };
+  __shared__ __attribute__((aligned(16))) Smem sm;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const FamDesc fd = a.fam[blockIdx.x];
+  const int f = threadIdx.x / K;                     // flank inside the family
+  const bool live = wave * FPW < fd.nx;              // wave-uniform: does this wave hold any flank?
+  const bool active = f < fd.nx;
+  const int n = fd.tile0 * 64 + (live ? f : 0);
+  (void)lane;
+
+  if (threadIdx.x < 16)
+  {
+    const int cls = threadIdx.x;
+    unsigned pk = 0;
+    if (cls < RAMX_NCLASS)
+      pk = ((unsigned)a.tab[cls][0] & 0xffu) | (((unsigned)a.tab[cls][1] & 0xffu) << 8) | (((unsigned)a.tab[cls][2] & 0xffu) << 16) |
+           (((unsigned)a.tab[cls][3] & 0xffu) << 24);
+    sm.tab[cls] = (int)pk;
+  }
+  if (threadIdx.x < 12) sm.vote[threadIdx.x >> 2][threadIdx.x & 3] = 0ULL;
+  __syncthreads();
+
+  CpLane ln;
+  ln.l = threadIdx.x % K;
+  ln.j0 = ln.l * C;
+  ln.lCge = ln.l * C * a.ge;
+  ln.lm1Cge = (ln.l - 1) * C * a.ge;
+  ln.pL0 = ln.l == 0; ln.pLast = ln.l == K - 1;
+  ln.pFull = ln.l < Cfg::LB; ln.pPart = ln.l == Cfg::LB; ln.pDead = ln.l > Cfg::LB;
+  ln.keyfix = 255 - ln.j0 - (C - 1);
+  ln.iW = W - ln.j0;
+  ln.ilo = ln.ihi = ln.iclo = ln.ichi = 0;
+
+  int m[C], e[C];
+  int high = 0, pos = 0, thigh = 0, tpos = 0;
+  const int2 bd = a.bounds[n];
+  long long max_ext = 0;
+  int max_row = -1, rows_done = 0, ovf = 0, stopped = 0;
+
+  // base words: the lane's window covers nibbles s .. s+C, s = j0 + r + 8; w[k] = word (s >> 3) + k, one word ahead
+  unsigned w[NWL + 1];
+  int s = ln.j0 + 7;                                 // r = -1
+  {
+    const int w0 = s >> 3;
+    static_for([&](auto kc) __attribute__((always_inline))
+    {
+      constexpr int k = decltype(kc)::value;
+      const int wi = (w0 + k < a.KW) ? w0 + k : a.KW - 1;
+      w[k] = a.bases[(size_t)wi * a.Np + n];
+    }, std::make_integer_sequence<int, NWL + 1>{});
+  }
+  const char *tb = reinterpret_cast<const char *>(&sm.tab[0]);
+
+  // ---- pieces of a column --------------------------------------------------------------------
+  // table rows of cells 0 .. C of this block (cell C: the candidates' base of the block's last cell)
+  auto lookups = [&](int (&T)[C + 1]) __attribute__((always_inline))
+  {
+    const int ph4 = 4 * (s & 7);
+    unsigned AE[NA], AO[NA];
+    static_for([&](auto kc) __attribute__((always_inline))
+    {
+      constexpr int k = decltype(kc)::value;
+      const unsigned A = __builtin_amdgcn_alignbit(w[k + 1], w[k], ph4);
+      AE[k] = (A << 2) & 0x3c3c3c3cu;                // byte b: 4 * (nibble 2b)
+      AO[k] = (A >> 2) & 0x3c3c3c3cu;                // byte b: 4 * (nibble 2b+1)
+    }, std::make_integer_sequence<int, NA>{});
+    static_for([&](auto ic) __attribute__((always_inline))
+    {
+      constexpr int i = decltype(ic)::value;
+      const unsigned src = (i & 1) ? AO[i >> 3] : AE[i >> 3];
+      const unsigned off = __builtin_amdgcn_ubfe(src, 8 * ((i & 7) >> 1), 8);
+      T[i] = *reinterpret_cast<const int *>(tb + off);
+    }, std::make_integer_sequence<int, C + 1>{});
+  };
+  auto set_masks = [&](int r) __attribute__((always_inline))
+  {
+    const int jlo = bd.x - r, jhi = bd.y - r;        // cell j of row r is in bounds iff jlo <= j <= jhi
+    ln.ilo = jlo - ln.j0;
+    ln.ihi = (jhi < B - 1 ? jhi : B - 1) - ln.j0;
+    ln.iclo = ln.ilo - 1;                            // candidate cell j' of row r+1 <-> cell j'+1 of row r
+    ln.ichi = (jhi - 1 < B - 1 ? jhi - 1 : B - 1) - ln.j0;
+  };
+  // clamp at 0, cap from below by high + CAPPENALTY (ram_extend.c:1042, 1052-1062); then slide the window by one base:
+  // one new word every eighth column, loaded a whole word ahead of its first use
+  auto finish_column = [&](const int (&bestA)[4], unsigned (&contrib)[4]) __attribute__((always_inline))
+  {
+    const int capv = high + a.cap;
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+    {
+      const int b = bestA[c] < 0 ? 0 : bestA[c];
+      contrib[c] = active ? (unsigned)((b >= capv) ? b : capv) : 0u;
+    }
+    s++;
+    if ((s & 7) == 0)
+    {
+      static_for([&](auto kc) __attribute__((always_inline)) { constexpr int k = decltype(kc)::value; w[k] = w[k + 1]; },
+                 std::make_integer_sequence<int, NWL>{});
+      const int wn = (s >> 3) + NWL;
+      w[NWL] = a.bases[(size_t)(wn < a.KW ? wn : a.KW - 1) * a.Np + n];
+    }
+  };
+  // vote sets rotate: column r reads set r % 3, adds to set (r+1) % 3 and clears set (r+2) % 3 (last read at the top of
+  // column r-1, next added to during column r+1; the barrier at the end of every column separates the three uses)
+  auto publish = [&](int r, unsigned (&contrib)[4]) __attribute__((always_inline))
+  {
+    if (live)
+    {
+      cp_flank_sum4<K>(contrib);
+      if (lane == 0)
+      {
+#pragma unroll
+        for (int c = 0; c < 4; c++) atomicAdd(&sm.vote[(r + 4) % 3][c], (unsigned long long)contrib[c]);
+      }
+    }
+    __syncthreads();
+  };
+
+  // ---- column -1: boundary row (ram_extend.c:909-946) and the candidates of row 0 -----------------
+  if (a.L > 0)
+  {
+    unsigned contrib[4] = { 0, 0, 0, 0 };
+    if (live)
+    {
+      int T[C + 1], bestA[4], bestF, jb;
+      lookups(T);
+      set_masks(-1);
+      static_for([&](auto ic) __attribute__((always_inline))
+      {
+        constexpr int i = decltype(ic)::value;
+        const int j = ln.j0 + i, o = j - W;
+        int v = (o == 0) ? 0 : a.go + (o < 0 ? -o : o) * a.ge;  // sub = gap = go + |o| * ge, 0 at the centre
+        v = (j < B) ? v : SENT;                                    // dead cells: sentinel
+        m[i] = v; e[i] = v + a.ge;                                 // e = max(sub + go, gap) + ge with go <= 0
+      }, std::make_integer_sequence<int, C>{});
+      cp_reduce<W, K, true>(ln, T, m, e, bestF, jb, bestA);
+      finish_column(bestA, contrib);
+    }
+    publish(-1, contrib);
+  }
+  for (int r = 0; r < a.L; r++)
+  {
+    // vote of row r: block-local (added during the previous column)
+    int besta = 0;
+    long long curr = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+    {
+      const unsigned long long vv = sm.vote[r % 3][k];
+      const long long vk = ((long long)__builtin_amdgcn_readfirstlane((int)(vv >> 32)) << 32) |
+                           (long long)(unsigned)__builtin_amdgcn_readfirstlane((int)vv);
+      if (vk > 2147483647LL || vk < -2147483648LL) ovf = 1;
+      if (vk > curr) { curr = vk; besta = k; }                   // ram_extend.c:1081-1085
+    }
+    int dist = max_row - r;
+    dist = dist < 0 ? -dist : dist;
+    const bool new_max = curr >= max_ext + (long long)dist * a.minimp;   // :1194-1196
+    if (new_max) { max_row = r; max_ext = curr; }
+    int d2 = r - max_row;
+    d2 = d2 < 0 ? -d2 : d2;
+    stopped = d2 >= a.when_to_stop;                              // :1216
+    rows_done = r + 1;
+    if (threadIdx.x == 0) a.cons_out[(size_t)fd.id * a.L + r] = (signed char)besta;
+    if (threadIdx.x < 4) sm.vote[(r + 2) % 3][threadIdx.x] = 0ULL;
+    unsigned contrib[4] = { 0, 0, 0, 0 };
+    if (live)
+    {
+      int T[C + 1], bestA[4], bestF, jb;
+      lookups(T);
+      const bool fast = __all(!active || ((bd.x - r <= 0) && (bd.y - r >= B)));
+      if (fast)
+      {
+        cp_update<W, K, false>(ln, a.go, a.ge, 8 * besta, 0, T, m, e);
+        cp_reduce<W, K, false>(ln, T, m, e, bestF, jb, bestA);
+      }
+      else
+      {
+        set_masks(r);
+        const int edgeFx = (r < W) ? a.go + (r + 1) * a.ge : SENT;
+        cp_update<W, K, true>(ln, a.go, a.ge, 8 * besta, edgeFx, T, m, e);
+        cp_reduce<W, K, true>(ln, T, m, e, bestF, jb, bestA);
+      }
+      if (bestF > high) { high = bestF; pos = r + jb - W; }      // ram_extend.c:1140-1150
+      if (new_max) { thigh = high; tpos = pos; }                 // :1203-1207
+      finish_column(bestA, contrib);
+    }
+    if (stopped || r == a.L - 1) break;
+    publish(r, contrib);
+  }
+  if (live && a.state_out != NULL && active)
+  {
+    static_for([&](auto ic) __attribute__((always_inline))
+    {
+      constexpr int i = decltype(ic)::value;
+      if (ln.j0 + i < B) a.state_out[(size_t)n * B + ln.j0 + i] = make_int2(m[i], e[i]);
+    }, std::make_integer_sequence<int, C>{});
+  }
+  if (live && ln.pL0) a.trim[n] = make_int2(thigh, tpos);
+  if (threadIdx.x == 0)
+  {
+    RamxCtl o;
+    o.max_ext = max_ext; o.max_row = max_row; o.stopped = stopped; o.rows_done = rows_done; o.overflow = ovf; o.besta = 0; o.pad = 0;
+    a.ctl_out[fd.id] = o;
+  }
+}

@@ -29,6 +29,7 @@ class RunInfo:
     kernel_samples: int
     prep_ms: float
     persistent: int = 0
+    lanes_per_flank: int = 1
 
 
 def _params(p: ExtendParams):

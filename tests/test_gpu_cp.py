@@ -1,0 +1,166 @@
+"""The cell-parallel band (csrc/ramx_kernels_cp.h): K = 2, 4, 8 or 16 lanes of a wavefront share one flank, the
+insertion chain of a row becomes a DPP prefix-max scan.  Every family must come out exactly as the oracle's serial
+loop does -- consensus, return values, extension lengths, scores, and the stored DP row cell by cell."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+from repeatafterme_amd import _lib
+from repeatafterme_amd.datamodel import CoreSet, new_master
+from repeatafterme_amd.extend import extend_batch
+from repeatafterme_amd.synth import synth_adversarial, synth_family
+
+from helpers import assert_same_result, gpu_extend, oracle_extend, run_both_directions, to_extend_params
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _cp_on(monkeypatch):
+    monkeypatch.delenv("RAMX_NO_CP", raising=False)
+    monkeypatch.delenv("RAMX_CP_K", raising=False)
+    yield
+
+
+def _families(k, L, W, sizes=(5, 16, 17, 31, 40, 64, 65, 100, 128, 129, 200, 256, 300, 512)):
+    fams = []
+    for i in range(k):
+        n = sizes[i % len(sizes)]
+        if i % 4 == 3:
+            fs = synth_adversarial(900 + i, n_windows=3 + i % 9, L=L, W=W, K=40 + 9 * (i % 7), lowercase=(i % 5 == 0))
+        else:
+            fs = synth_family(n, L, W, K=50 + 17 * (i % 9), seed=700 + i, both_sides=True, minus_frac=0.3,
+                              n_run_frac=0.15, core_len=(10 if i % 3 else 2 * W + 5))
+        fams.append(fs)
+    return fams
+
+
+def _check_batch(fams, p, min_cp=1):
+    want = []
+    for fs in fams:
+        c = fs.cores.copy(); m = new_master(p.L)
+        r1 = po.oracle_extend(1, c, fs.sequence, m, p)
+        r0 = po.oracle_extend(0, c, fs.sequence, m, p)
+        want.append((r1.ret, r0.ret, r1.rows_executed, r0.rows_executed, m, c))
+    got_c = [fs.cores.copy() for fs in fams]
+    got_m = [new_master(p.L) for _ in fams]
+    ep = to_extend_params(p)
+    ir = extend_batch(1, [(c, fs.sequence, m) for c, fs, m in zip(got_c, fams, got_m)], ep)
+    il = extend_batch(0, [(c, fs.sequence, m) for c, fs, m in zip(got_c, fams, got_m)], ep)
+    for i, (w, c, m) in enumerate(zip(want, got_c, got_m)):
+        tag = f"family {i} ({fams[i].cores.n} cores, lanes/flank {ir[i].lanes_per_flank}/{il[i].lanes_per_flank})"
+        assert (ir[i].ret, il[i].ret, ir[i].rows_executed, il[i].rows_executed) == w[:4], tag
+        assert np.array_equal(m, w[4]), tag + ": consensus"
+        assert np.array_equal(c.left_len, w[5].left_len) and np.array_equal(c.right_len, w[5].right_len), tag
+        assert np.array_equal(c.score, w[5].score), tag
+    lanes = [x.lanes_per_flank for x in ir + il]
+    assert sum(1 for x in lanes if x > 1) >= min_cp, lanes
+    return lanes
+
+
+@pytest.mark.parametrize("W,matrix", [(40, "14p43g"), (14, "20p43g"), (20, "repeatscout"), (80, "20p43g"), (40, "25p43g")])
+def test_cp_batch_equals_oracle(W, matrix):
+    L = 180
+    p = po.Params.named(matrix, bandwidth=W, L=L, when_to_stop=30)
+    lanes = _check_batch(_families(28, L, W), p, min_cp=20)
+    assert 16 in lanes and 8 in lanes
+
+
+@pytest.mark.parametrize("K", [2, 4, 8])
+@pytest.mark.parametrize("W", [14, 20, 40])
+def test_cp_forced_lanes_per_flank(W, K, monkeypatch):
+    """RAMX_CP_K caps the lanes per flank, so that every scan / reduction shape (quad, half row, row) runs on small
+    families too; shapes whose block would exceed the register budget fall back to more lanes or to lane-per-flank."""
+    monkeypatch.setenv("RAMX_CP_K", str(K))
+    L = 120
+    p = po.Params.named("18p43g", bandwidth=W, L=L, when_to_stop=25)
+    _check_batch(_families(14, L, W, sizes=(3, 16, 33, 64, 100, 130, 250)), p, min_cp=0)
+
+
+def test_cp_stop_rule_and_degenerate_inputs():
+    fs = synth_family(100, 90, 14, K=50, seed=17, both_sides=True, minus_frac=0.3)
+    for kw in (dict(when_to_stop=0), dict(when_to_stop=1), dict(L=1), dict(L=2, when_to_stop=1), dict(minimprovement=-3),
+               dict(cappenalty=0), dict(L=51, when_to_stop=1), dict(L=70, when_to_stop=20), dict(when_to_stop=1000)):
+        args = dict(bandwidth=14, L=90, when_to_stop=100)
+        args.update(kw)
+        p = po.Params.named("20p43g", **args)
+        a = run_both_directions(oracle_extend, fs.cores, fs.sequence, p)
+        b = run_both_directions(gpu_extend, fs.cores, fs.sequence, p)
+        assert_same_result(a[0], a[1], a[2:], b[0], b[1], b[2:], str(kw))
+        assert b[2].lanes_per_flank == 8 and b[3].lanes_per_flank == 8
+        assert (a[2].rows_executed, a[2].limit_warning, a[3].rows_executed, a[3].limit_warning) == \
+               (b[2].rows_executed, b[2].limit_warning, b[3].rows_executed, b[3].limit_warning), str(kw)
+    seq = np.array([0, 1, 2, 3] * 40, np.int8)
+    p = po.Params.named("14p43g", bandwidth=14, L=40, when_to_stop=10)
+    for c in (CoreSet(left_pos=[50], right_pos=[52], lower=[0], upper=[159], orient=[0], left_ext=[1], right_ext=[1]),
+              CoreSet(left_pos=[50, 90], right_pos=[52, 99], lower=[0, 60], upper=[159, 110], orient=[0, 1], left_ext=[1, 1], right_ext=[1, 1])):
+        a = run_both_directions(oracle_extend, c, seq, p)
+        b = run_both_directions(gpu_extend, c, seq, p)
+        assert_same_result(a[0], a[1], a[2:], b[0], b[1], b[2:], "degenerate")
+        assert a[2].rows_executed == b[2].rows_executed and b[2].lanes_per_flank == 16
+
+
+@pytest.mark.parametrize("W,n,K", [(9 + 5, 40, 16), (20, 100, 8), (40, 200, 4), (80, 60, 16), (40, 30, 16)])
+def test_cp_state_bit_exact_per_cell(W, n, K, monkeypatch):
+    """After L columns the DP row kept by the cell-parallel kernel equals the oracle's row, cell by cell, both states
+    (what bnw_extend.c:1617-1648 asserts for the reference): the scan re-associates the insertion chain exactly."""
+    monkeypatch.setenv("RAMX_CP_PEEK", "1")
+    L = 45
+    fs = synth_family(n, 70, W, K=40, seed=21 + W, both_sides=True, minus_frac=0.4, n_run_frac=0.2,
+                      core_len=(2 * W + 3 if W != 20 else 7))
+    p = po.Params.named("18p43g", bandwidth=W, L=L, when_to_stop=1000)
+    lib = _lib.lib()
+    B = 2 * W + 1
+    from repeatafterme_amd.device import resolve_flanks
+    for direction in (1, 0):
+        c = fs.cores.copy(); m = new_master(L)
+        info = gpu_extend(direction, c, fs.sequence, m, p)
+        assert info.rows_executed == L and info.lanes_per_flank == K
+        cons = m[L + 1: 2 * L + 1] if direction else m[L - 1::-1][:L]
+        _, idx = resolve_flanks(direction, fs.cores, W, L)
+        n_align = fs.cores.n
+        score = np.zeros((2, n_align, B, 2), np.int32)
+        for o in range(-W, W + 1):
+            score[1, :, o + W, :] = 0 if o == 0 else abs(o) * p.gapextn + p.gapopen
+        cc = fs.cores
+        for row in range(L):
+            for k in idx:
+                po.oracle_nw_row(direction, row, int(k), n_align, int(cons[row]), int(cc.left_pos[k]), int(cc.right_pos[k]),
+                                 int(cc.orient[k]), score, int(cc.lower[k]), int(cc.upper[k]), fs.sequence,
+                                 p.matrix, p.gapopen, p.gapextn, W)
+        for i in (0, 1, len(idx) // 2, len(idx) - 1):
+            cells = np.zeros((B, 2), np.int32)
+            rc = lib.ramx_dev_peek_family_state(None, int(i), cells.ctypes.data_as(C.c_void_p))
+            assert rc == 0, lib.ramx_last_error()
+            k = idx[i]
+            sub, gap = score[(L - 1) % 2, k, :, 0].astype(np.int64), score[(L - 1) % 2, k, :, 1].astype(np.int64)
+            want = np.stack([np.maximum(sub, gap), np.maximum(sub + p.gapopen, gap) + p.gapextn], axis=1)
+            assert np.array_equal(cells, want), f"W {W} dir {direction} flank {i}: cells {np.nonzero((cells != want).any(axis=1))[0][:8]}"
+
+
+def test_cp_scoring_bounds_fall_back(monkeypatch):
+    """Scores outside int8 or large enough to leave the 23-bit key range must not take the cell-parallel kernel."""
+    fs = synth_family(60, 120, 14, K=80, seed=5, both_sides=True)
+    base = po.Params.named("14p43g", bandwidth=14, L=120, when_to_stop=30)
+    ref = run_both_directions(oracle_extend, fs.cores, fs.sequence, base)
+    got = run_both_directions(gpu_extend, fs.cores, fs.sequence, base)
+    assert_same_result(ref[0], ref[1], ref[2:], got[0], got[1], got[2:], "base")
+    assert got[2].lanes_per_flank == 16
+    q = po.Params(**{f: getattr(base, f) for f in ("bandwidth", "cappenalty", "minimprovement", "L", "when_to_stop", "l",
+                                                   "gapopen", "gapextn", "matrix")})
+    mm = q.matrix.astype(np.int64).copy().reshape(100, 100)
+    for a in range(4):
+        for b in list(range(8)) + [99]:
+            mm[a, b] *= 20
+    q.matrix = mm.reshape(-1).astype(np.int32)
+    q.gapopen *= 20; q.gapextn *= 20; q.cappenalty *= 20; q.minimprovement *= 20
+    a = run_both_directions(oracle_extend, fs.cores, fs.sequence, q)
+    b = run_both_directions(gpu_extend, fs.cores, fs.sequence, q)
+    assert_same_result(a[0], a[1], a[2:], b[0], b[1], b[2:], "x20")
+    assert b[2].lanes_per_flank == 1
+    monkeypatch.setenv("RAMX_NO_CP", "1")
+    got = run_both_directions(gpu_extend, fs.cores, fs.sequence, base)
+    assert_same_result(ref[0], ref[1], ref[2:], got[0], got[1], got[2:], "NO_CP")
+    assert got[2].lanes_per_flank == 1
