@@ -6,7 +6,7 @@ import os
 import subprocess
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libramx.so")
+LIB_PATH = os.environ.get("RAMX_LIB") or os.path.join(_PKG, "libramx.so")   # RAMX_LIB: A/B builds (tools/build_variant.sh)
 CLI_PATH = os.path.join(_PKG, "RAMExtend")
 
 # every symbol include/ramx.h declares (tests/test_cabi.py checks the .so exports all of them)

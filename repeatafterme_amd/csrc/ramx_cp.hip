@@ -5,10 +5,10 @@
 
 #include <stdlib.h>
 
-#define CP_MAX_CELLS 21      // cells per lane up to which the row (2 registers per cell) and its temporaries fit 128 VGPRs
-
 static bool cp_has_width(int W) { return W == 14 || W == 20 || W == 40 || W == 80; }
 static int cp_cells(int W, int K) { return (2 * W + 1 + K - 1) / K; }
+// workgroup size limit of a block of C cells per lane (register budget, CpCfg::MAXT)
+static int cp_max_threads(int W, int C) { (void)W; return C <= 41 ? 512 : 0; }
 
 int ramx_cp_max_family(int W, int go, int ge, const int (&tab)[RAMX_NCLASS][4], int L)
 {
@@ -27,24 +27,30 @@ int ramx_cp_max_family(int W, int go, int ge, const int (&tab)[RAMX_NCLASS][4], 
   if (-(long long)ge * 200 >= (1LL << 23)) return 0;
   int best = 0;
   for (int K = 16; K >= 2; K >>= 1)
-    if (cp_cells(W, K) <= CP_MAX_CELLS) best = 1024 / K;
+  {
+    const int t = cp_max_threads(W, cp_cells(W, K));
+    if (t / K > best) best = t / K;
+  }
   return best;
 }
 
+// A family takes the most lanes per flank (16, 8, 4, 2) that keep it within one 512-thread workgroup; the classes are
+// (lanes per flank, workgroup size): families of up to 16 flanks run 16 lanes per flank in 256 threads.
 int ramx_cp_class(int W, int nx, int *K, int *threads)
 {
-  static const int cls_nx[RAMX_CP_NCLASS] = { 16, 32, 64, 128, 256, 512 };
-  static const int cls_k[RAMX_CP_NCLASS] = { 16, 16, 16, 8, 4, 2 };
+  static const int cls_k[RAMX_CP_NCLASS] = { 16, 16, 8, 4, 2, 0 };
+  static const int cls_t[RAMX_CP_NCLASS] = { 256, 512, 512, 512, 512, 0 };
   const char *fk = getenv("RAMX_CP_K");              // test hook: at most this many lanes per flank
   const int force = fk ? atoi(fk) : 0;
   for (int c = 0; c < RAMX_CP_NCLASS; c++)
   {
-    if (nx > cls_nx[c]) continue;
-    int k = cls_k[c];
-    if (force >= 2 && force < k) k = force;
-    if (cp_cells(W, k) > CP_MAX_CELLS) continue;
+    const int k = cls_k[c];
+    if (k == 0 || (force >= 2 && k > force)) continue;
+    int t = cp_max_threads(W, cp_cells(W, k));
+    if (t > cls_t[c]) t = cls_t[c];
+    if (t == 0 || nx * k > t) continue;
     *K = k;
-    *threads = ((cls_nx[c] * k + 63) / 64) * 64;
+    *threads = t;
     return c;
   }
   return -1;
@@ -53,9 +59,13 @@ int ramx_cp_class(int W, int nx, int *K, int *threads)
 template <int W, int K>
 static int cp_launch(hipStream_t st, int threads, int F, const CPArgs &a)
 {
-  if (CpCfg<W, K>::C > CP_MAX_CELLS) return RAMX_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL((ramx_cp_family_kernel<W, (CpCfg<W, K>::C > CP_MAX_CELLS ? 16 : K)>), dim3(F), dim3(threads), 0, st, a);
-  return hipGetLastError() == hipSuccess ? RAMX_OK : RAMX_ERR_HIP;
+  if constexpr (CpCfg<W, K>::MAXT == 0) return RAMX_ERR_UNSUPPORTED;
+  else
+  {
+    if (threads > CpCfg<W, K>::MAXT) return RAMX_ERR_ARG;
+    hipLaunchKernelGGL((ramx_cp_family_kernel<W, K>), dim3(F), dim3(threads), 0, st, a);
+    return hipGetLastError() == hipSuccess ? RAMX_OK : RAMX_ERR_HIP;
+  }
 }
 
 template <int W>

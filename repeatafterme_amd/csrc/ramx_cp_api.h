@@ -17,6 +17,7 @@ struct CPArgs
   int2 *state_out;              // optional (tests): final rows, [flank][2W+1] (m, e), else NULL
   int Np, KW, L, go, ge, cap, minimp, when_to_stop;
   int tab[RAMX_NCLASS][4];
+  unsigned long long *dbg;      // -DRAMX_CP_TIMING builds only: [wave of block 0][8] phase sums in shader clocks
 };
 
 #define RAMX_CP_NCLASS 6

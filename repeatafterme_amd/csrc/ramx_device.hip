@@ -700,6 +700,7 @@ extern "C" int ramx_dev_run_families(ramx_dev *d, const ramx_flank *flanks, int3
   RamxCtl *hctl = NULL;
   int2 *tmp = NULL;
   float ms = 0;
+  unsigned long long *cp_dbg = NULL;
 #define FAMCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
     ramx_set_error("HIP error %s at %s:%d (%s)", hipGetErrorString(e_), __FILE__, __LINE__, #call); rc = RAMX_ERR_HIP; goto done; } } while (0)
   FamDesc *dfd; RamxCtl *dctl;
@@ -761,6 +762,11 @@ extern "C" int ramx_dev_run_families(ramx_dev *d, const ramx_flank *flanks, int3
       ca.state_out = (int2 *)d->d_cpstate;
       d->cpstate_W = W; d->cpstate_n = Np;
     }
+#ifdef RAMX_CP_TIMING
+    FAMCHK(hipMalloc((void **)&ca.dbg, (16 * 8 + 8) * sizeof(unsigned long long)));
+    FAMCHK(hipMemset(ca.dbg, 0, (16 * 8 + 8) * sizeof(unsigned long long)));
+    cp_dbg = ca.dbg;
+#endif
     for (int c = 0; c < RAMX_CP_NCLASS; c++)
     {
       if (cls_count[c] == 0) continue;
@@ -840,6 +846,22 @@ extern "C" int ramx_dev_run_families(ramx_dev *d, const ramx_flank *flanks, int3
   }
   if (fa.dbg) (void)hipFree(fa.dbg);
 #endif
+#ifdef RAMX_CP_TIMING
+  if (cp_dbg)
+  {
+    unsigned long long h[16 * 8 + 8];
+    FAMCHK(hipMemcpy(h, cp_dbg, sizeof(h), hipMemcpyDeviceToHost));
+    static const char *nm[8] = { "vote read + stop rule", "lookups issued", "row update (fast)", "reductions (fast)", "masked/records/slide",
+                                 "sum+atomics+barrier", "-", "loop top" };
+    const double cols = h[16 * 8] ? (double)h[16 * 8] : 1.0;
+    fprintf(stderr, "CP_TIMING block 0, %.0f columns, shader clocks per column (waves 0, 1, last two):\n", cols);
+    int nw = 0;
+    for (int w = 0; w < 16; w++) if (h[w * 8 + 0]) nw = w + 1;
+    for (int k = 0; k < 8; k++)
+      if (k != 6) fprintf(stderr, "CP_TIMING %-24s w0 %7.1f  w1 %7.1f  w%d %7.1f  w%d %7.1f\n", nm[k], h[k] / cols, h[8 + k] / cols,
+                          nw > 1 ? nw - 2 : 0, h[(nw > 1 ? nw - 2 : 0) * 8 + k] / cols, nw > 0 ? nw - 1 : 0, h[(nw > 0 ? nw - 1 : 0) * 8 + k] / cols);
+  }
+#endif
   hctl = (RamxCtl *)malloc(sizeof(RamxCtl) * n_families);
   FAMCHK(hipMemcpy(hctl, dctl, sizeof(RamxCtl) * n_families, hipMemcpyDeviceToHost));
   if (cons && L > 0) FAMCHK(hipMemcpy(cons, d->d_cons, (size_t)n_families * L, hipMemcpyDeviceToHost));
@@ -866,6 +888,7 @@ extern "C" int ramx_dev_run_families(ramx_dev *d, const ramx_flank *flanks, int3
   rc = RAMX_OK;
 done:
 #undef FAMCHK
+  if (cp_dbg) (void)hipFree(cp_dbg);
   free(hctl); free(tmp); free(hfd); free(grp);
   d->ready = 0;       // the single-family buffers were reused: begin_direction must be called again before run_direction
   return rc;

@@ -30,6 +30,12 @@
 
 #define CP_IDN (-1500000000)      // identity of the max scans: below every value a live cell can hold, far from INT_MIN
 #define CP_IMIN (-2147483647 - 1)
+#ifndef CP_G_GROUP
+#define CP_G_GROUP 2          // masked path: cells per scheduling group
+#endif
+#ifndef CP_F_GROUP
+#define CP_F_GROUP 4          // fast path: cells per scheduling group (bounds the live ranges of the per-cell temporaries)
+#endif
 
 #define CP_QP(a, b, c, d) "quad_perm:[" #a "," #b "," #c "," #d "]"
 
@@ -102,6 +108,11 @@ struct CpCfg
   static constexpr int IB = (B - 1) % C;             // its index there
   static constexpr int NA = (C + 1 + 7) / 8;         // aligned 8-nibble windows covering the C+1 lookups of a row
   static constexpr int NWL = (C + 7) / 8 + 1;        // base words spanned by nibbles s .. s+C
+  // Workgroups have at most 512 threads (two waves per SIMD, 256 VGPRs each): measured on one CU, a family runs
+  // fastest on 4-8 waves -- fewer, longer blocks per lane beat more lanes per flank once every SIMD has a wave or two,
+  // because the scan / reduction / vote cost is per wave (tools/cp_cmp_k.sh: 100 flanks at W = 40: 2.58 us per column
+  // with 4 lanes per flank, 2.95 with 8).  Blocks of up to 41 cells fit that register budget.
+  static constexpr int MAXT = C <= 41 ? 512 : 0;
 };
 
 // per-lane constants of the cell-parallel band
@@ -113,11 +124,31 @@ struct CpLane
   bool pL0, pLast;       // l == 0, l == K-1
   bool pFull, pPart, pDead;   // l < LB, l == LB, l > LB
   int keyfix;            // 255 - j0 - (C-1): turns a block-local key into a band-global one
-  // per row (masked path)
-  int ilo, ihi;          // cell i of this lane is in bounds iff ilo <= i <= ihi (dead cells excluded)
-  int iclo, ichi;        // candidate cell i (row r+1) is in bounds iff iclo <= i <= ichi
-  int iW;                // cells i < iW have band index j < W (edge fill in the first W rows)
+  // per row (masked path): intervals as (negated lower end, span) for one unsigned compare per cell;
+  // an empty interval is (-(1 << 20), 0)
+  int nlo, span;         // cell i of this lane is in bounds iff (unsigned)(i + nlo) <= span (dead cells excluded)
+  int nclo, cspan;       // candidate cell i (row r+1) is in bounds iff (unsigned)(i + nclo) <= cspan
+  int iW;                // cells i < iW have band index j < W
+  int iWr;               // iW in the first W rows, else a value no cell index reaches: edge fill applies iff i < iWr
 };
+
+// Selects of the masked path.  A comparison and the select that consumes it are ONE asm statement joined through VCC:
+// written as C++ the (loop-invariant or early-computable) predicates of a whole block are hoisted by the scheduler into
+// dozens of SGPR pairs, which spill into vector registers and from there into scratch.  volatile: otherwise the fills of
+// pass 1 are kept alive (common subexpressions) for the fix-up pass, one more register per cell.
+__device__ __forceinline__ int cp_sel_in(int ipn /* i + nlo */, int span, int inside, int outside)
+{
+  int d;
+  asm volatile("v_cmp_ge_u32 vcc, %1, %2\n\tv_cndmask_b32 %0, %4, %3, vcc" : "=v"(d) : "v"(span), "v"(ipn), "v"(inside), "v"(outside) : "vcc");
+  return d;
+}
+template <int I>
+__device__ __forceinline__ int cp_fill(int iWr, int edge)      // (I < iWr) ? edge : SENT      (bnw_extend.c:990-1002)
+{
+  int d, sent = SENT;
+  asm volatile("v_cmp_lt_i32 vcc, %1, %2\n\tv_cndmask_b32 %0, %4, %3, vcc" : "=v"(d) : "n"(I), "v"(iWr), "v"(edge), "v"(sent) : "vcc");
+  return d;
+}
 
 // Row r from row r-1 (bnw_extend.c:750-1048), cells split over the group.  G: masked (general) path.
 template <int W, int K, bool G>
@@ -126,6 +157,19 @@ __device__ __forceinline__ void cp_update(const CpLane &ln, const int go, const 
 {
   typedef CpCfg<W, K> Cfg;
   constexpr int C = Cfg::C, IB = Cfg::IB;
+  if (G)
+  {
+    // The masked and the fast variant start with the same arithmetic on every cell (score lookup, substitution term);
+    // left alone, the optimiser hoists those 2C values above the branch that selects the variant and keeps them alive
+    // across it.  Opaque copies of the row make the two instruction streams different.
+    static_for([&](auto ic) __attribute__((always_inline))
+    {
+      constexpr int i = decltype(ic)::value;
+      int x = m[i];
+      asm("" : "+v"(x));
+      m[i] = x;
+    }, std::make_integer_sequence<int, C>{});
+  }
   // previous row's e of the cell right of this block: the deletion term of the block's last cell
   int peNext = e[0];
   asm("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_shl:1 " CP_FULL : "=v"(peNext) : "v"(e[0]), "0"(NEG));   // lane 15 of a row keeps NEG
@@ -136,6 +180,8 @@ __device__ __forceinline__ void cp_update(const CpLane &ln, const int go, const 
   static_for([&](auto ic) __attribute__((always_inline))
   {
     constexpr int i = decltype(ic)::value;
+    // masked path: keep the scheduler from hoisting every cell's fills and range tests to the top of the block
+    if constexpr ((i % (G ? CP_G_GROUP : CP_F_GROUP)) == 0) __builtin_amdgcn_sched_barrier(0);
     const int sF = __builtin_amdgcn_sbfe(T[i], sh8, 8);          // M[besta][base]: byte `besta` of the packed scores
     const int sub = m[i] + sF;                                   // :950-956
     int del = peNext;                                            // :892-905
@@ -144,12 +190,7 @@ __device__ __forceinline__ void cp_update(const CpLane &ln, const int go, const 
     if constexpr (!G && i == IB + 1) eprev = ln.pPart ? CP_IDN : eprev;   // cut the chain into the dead cells
     const int mN = vmax3(sub, del, eprev);                       // :1007-1018
     int eN = vmax3(sub + go, del, eprev) + ge;
-    if (G)
-    {
-      const bool inb = (i >= ln.ilo) && (i <= ln.ihi);
-      const int vF = (i < ln.iW) ? edgeFx : SENT;                // :990-1002
-      eN = inb ? eN : vF + ge;                                   // an out-of-bounds cell restarts the chain
-    }
+    if (G) eN = cp_sel_in(i + ln.nlo, ln.span, eN, cp_fill<i>(ln.iWr, edgeFx) + ge);   // an out-of-bounds cell restarts the chain
     m[i] = mN; e[i] = eN; eprev = eN;
   }, std::make_integer_sequence<int, C>{});
   // carry: e of the cell left of the block = max over the lanes to the left of (their total decayed by ge per cell)
@@ -164,16 +205,16 @@ __device__ __forceinline__ void cp_update(const CpLane &ln, const int go, const 
   static_for([&](auto ic) __attribute__((always_inline))
   {
     constexpr int i = decltype(ic)::value;
+    if constexpr ((i % (G ? CP_G_GROUP : CP_F_GROUP)) == 0) __builtin_amdgcn_sched_barrier(0);
     if constexpr (!G && i == IB + 1) c = ln.pPart ? CP_IDN : c;
     int mi = imax(m[i], c);
     c += ge;
     int ei = imax(e[i], c);
     if (G)
     {
-      const bool inb = (i >= ln.ilo) && (i <= ln.ihi);
-      const int vF = (i < ln.iW) ? edgeFx : SENT;
-      mi = inb ? mi : vF;
-      ei = inb ? ei : vF + ge;
+      const int vF = cp_fill<i>(ln.iWr, edgeFx), ipn = i + ln.nlo;
+      mi = cp_sel_in(ipn, ln.span, mi, vF);
+      ei = cp_sel_in(ipn, ln.span, ei, vF + ge);
     }
     m[i] = mi; e[i] = ei;
   }, std::make_integer_sequence<int, C>{});
@@ -192,11 +233,12 @@ __device__ __forceinline__ void cp_reduce(const CpLane &ln, const int (&T)[CpCfg
   static_for([&](auto ic) __attribute__((always_inline))
   {
     constexpr int i = decltype(ic)::value;
+    if constexpr ((i % (G ? CP_G_GROUP : CP_F_GROUP)) == 0) __builtin_amdgcn_sched_barrier(0);
     int key = (int)(((unsigned)m[i] << 8) | (unsigned)(C - 1 - i));
-    if (G) key = ((i >= ln.ilo) && (i <= ln.ihi)) ? key : CP_IMIN;
+    if (G) key = cp_sel_in(i + ln.nlo, ln.span, key, CP_IMIN);
     else if constexpr (i > IB) key = ln.pFull ? key : CP_IMIN;
     int ms = m[i];
-    if (G) ms = ((i >= ln.iclo) && (i <= ln.ichi)) ? ms : SENT;
+    if (G) ms = cp_sel_in(i + ln.nclo, ln.cspan, ms, SENT);
     const int t4[4] = { add_sext_byte<0>(ms, T[i + 1]), add_sext_byte<1>(ms, T[i + 1]), add_sext_byte<2>(ms, T[i + 1]),
                         add_sext_byte<3>(ms, T[i + 1]) };
     int ev = e[i];
@@ -232,8 +274,15 @@ __device__ __forceinline__ void cp_reduce(const CpLane &ln, const int (&T)[CpCfg
 // ------------------------------------------------------------------------------------------
 // one workgroup = one family, K lanes per flank
 // ------------------------------------------------------------------------------------------
+#ifdef RAMX_CP_TIMING
+#define CP_TICK(k) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+                        __builtin_amdgcn_sched_barrier(0); tsum[k] += t_ - tlast; tlast = t_; } while (0)
+#else
+#define CP_TICK(k) do { } while (0)
+#endif
+
 template <int W, int K>
-__global__ __launch_bounds__(1024) void ramx_cp_family_kernel(const CPArgs a)
+__global__ __launch_bounds__((CpCfg<W, K>::MAXT > 0 ? CpCfg<W, K>::MAXT : 64)) void ramx_cp_family_kernel(const CPArgs a)
 {
   typedef CpCfg<W, K> Cfg;
   constexpr int B = Cfg::B, C = Cfg::C, NA = Cfg::NA, NWL = Cfg::NWL, FPW = 64 / K;
@@ -245,7 +294,9 @@ __global__ __launch_bounds__(1024) void ramx_cp_family_kernel(const CPArgs a)
     unsigned long long vote[3][4];
   };
   __shared__ __attribute__((aligned(16))) Smem sm;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // wave index through readfirstlane: `live` must be PROVABLY wave-uniform, or the band sits in a divergent region and
+  // every column ends with one predicated copy per state register (phi of old and new row)
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const FamDesc fd = a.fam[blockIdx.x];
   const int f = threadIdx.x / K;                     // flank inside the family
   const bool live = wave * FPW < fd.nx;              // wave-uniform: does this wave hold any flank?
@@ -274,8 +325,13 @@ __global__ __launch_bounds__(1024) void ramx_cp_family_kernel(const CPArgs a)
   ln.pFull = ln.l < Cfg::LB; ln.pPart = ln.l == Cfg::LB; ln.pDead = ln.l > Cfg::LB;
   ln.keyfix = 255 - ln.j0 - (C - 1);
   ln.iW = W - ln.j0;
-  ln.ilo = ln.ihi = ln.iclo = ln.ichi = 0;
+  ln.nlo = ln.span = ln.nclo = ln.cspan = ln.iWr = 0;
 
+  // go and ge live in VECTOR registers on purpose: on gfx950 v_add_u32 issues at twice the rate with two VGPR operands
+  // (tools/microbench/valu_rate.hip: 2 cycles per wave-instruction, 4 with an SGPR operand); the empty asm hides from
+  // the compiler that the values are uniform
+  int vgo = a.go, vge = a.ge;
+  asm volatile("" : "+v"(vgo), "+v"(vge));
   int m[C], e[C];
   int high = 0, pos = 0, thigh = 0, tpos = 0;
   const int2 bd = a.bounds[n];
@@ -320,10 +376,14 @@ __global__ __launch_bounds__(1024) void ramx_cp_family_kernel(const CPArgs a)
   auto set_masks = [&](int r) __attribute__((always_inline))
   {
     const int jlo = bd.x - r, jhi = bd.y - r;        // cell j of row r is in bounds iff jlo <= j <= jhi
-    ln.ilo = jlo - ln.j0;
-    ln.ihi = (jhi < B - 1 ? jhi : B - 1) - ln.j0;
-    ln.iclo = ln.ilo - 1;                            // candidate cell j' of row r+1 <-> cell j'+1 of row r
-    ln.ichi = (jhi - 1 < B - 1 ? jhi - 1 : B - 1) - ln.j0;
+    const int ilo = jlo - ln.j0, ihi = (jhi < B - 1 ? jhi : B - 1) - ln.j0;
+    const int iclo = ilo - 1;                        // candidate cell j' of row r+1 <-> cell j'+1 of row r
+    const int ichi = (jhi - 1 < B - 1 ? jhi - 1 : B - 1) - ln.j0;
+    ln.nlo = (ihi >= ilo) ? -ilo : -(1 << 20);
+    ln.span = (ihi >= ilo) ? ihi - ilo : 0;
+    ln.nclo = (ichi >= iclo) ? -iclo : -(1 << 20);
+    ln.cspan = (ichi >= iclo) ? ichi - iclo : 0;
+    ln.iWr = (r < W) ? ln.iW : -(1 << 20);
   };
   // clamp at 0, cap from below by high + CAPPENALTY (ram_extend.c:1042, 1052-1062); then slide the window by one base:
   // one new word every eighth column, loaded a whole word ahead of its first use
@@ -358,17 +418,22 @@ __global__ __launch_bounds__(1024) void ramx_cp_family_kernel(const CPArgs a)
         for (int c = 0; c < 4; c++) atomicAdd(&sm.vote[(r + 4) % 3][c], (unsigned long long)contrib[c]);
       }
     }
-    __syncthreads();
+    // LDS traffic only: the barrier must not wait for the global accesses in flight (the base word loaded for eight
+    // columns ahead, the consensus byte) as __syncthreads() would
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   };
 
+  // The table rows of a column depend only on the base stream: they are fetched at the end of the previous column,
+  // ahead of the vote exchange, so that their LDS latency never sits in front of the band.
+  int T[C + 1];
+  if (live) lookups(T);
   // ---- column -1: boundary row (ram_extend.c:909-946) and the candidates of row 0 -----------------
   if (a.L > 0)
   {
     unsigned contrib[4] = { 0, 0, 0, 0 };
     if (live)
     {
-      int T[C + 1], bestA[4], bestF, jb;
-      lookups(T);
+      int bestA[4], bestF, jb;
       set_masks(-1);
       static_for([&](auto ic) __attribute__((always_inline))
       {
@@ -380,23 +445,34 @@ __global__ __launch_bounds__(1024) void ramx_cp_family_kernel(const CPArgs a)
       }, std::make_integer_sequence<int, C>{});
       cp_reduce<W, K, true>(ln, T, m, e, bestF, jb, bestA);
       finish_column(bestA, contrib);
+      lookups(T);
     }
     publish(-1, contrib);
   }
-  for (int r = 0; r < a.L; r++)
+#ifdef RAMX_CP_TIMING
+  unsigned long long tsum[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, tlast = __builtin_amdgcn_s_memtime();
+#endif
+  // One column.  The fast and the masked variant are two separate loops below (a wave switches between them when its
+  // flanks enter or leave the band's range): with both variants in ONE loop body the register allocator needed ~45
+  // registers more than the larger of the two.  Returns true when the column loop ends.
+  auto column = [&](const int r, auto gc) __attribute__((always_inline)) -> bool
   {
-    // vote of row r: block-local (added during the previous column)
+    constexpr bool G = decltype(gc)::value;
+    CP_TICK(7);                  // barrier released .. loop top
+    // vote of row r: block-local (added during the previous column).  The sums are non-negative: they are compared
+    // as (high, low) unsigned halves on the scalar unit (there is no 64-bit scalar compare; the compiler's choice for a
+    // signed 64-bit compare is a chain of vector instructions)
     int besta = 0;
-    long long curr = 0;
+    unsigned chi = 0, clo = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++)
     {
       const unsigned long long vv = sm.vote[r % 3][k];
-      const long long vk = ((long long)__builtin_amdgcn_readfirstlane((int)(vv >> 32)) << 32) |
-                           (long long)(unsigned)__builtin_amdgcn_readfirstlane((int)vv);
-      if (vk > 2147483647LL || vk < -2147483648LL) ovf = 1;
-      if (vk > curr) { curr = vk; besta = k; }                   // ram_extend.c:1081-1085
+      const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(vv >> 32)), lo = (unsigned)__builtin_amdgcn_readfirstlane((int)vv);
+      if (hi != 0 || lo > 2147483647u) ovf = 1;                  // the reference's int accumulator would have wrapped
+      if (hi > chi || (hi == chi && lo > clo)) { chi = hi; clo = lo; besta = k; }   // ram_extend.c:1081-1085
     }
+    const long long curr = (long long)(((unsigned long long)chi << 32) | clo);
     int dist = max_row - r;
     dist = dist < 0 ? -dist : dist;
     const bool new_max = curr >= max_ext + (long long)dist * a.minimp;   // :1194-1196
@@ -408,30 +484,67 @@ __global__ __launch_bounds__(1024) void ramx_cp_family_kernel(const CPArgs a)
     if (threadIdx.x == 0) a.cons_out[(size_t)fd.id * a.L + r] = (signed char)besta;
     if (threadIdx.x < 4) sm.vote[(r + 2) % 3][threadIdx.x] = 0ULL;
     unsigned contrib[4] = { 0, 0, 0, 0 };
+    CP_TICK(0);                  // vote read, stop rule
     if (live)
     {
-      int T[C + 1], bestA[4], bestF, jb;
-      lookups(T);
-      const bool fast = __all(!active || ((bd.x - r <= 0) && (bd.y - r >= B)));
-      if (fast)
-      {
-        cp_update<W, K, false>(ln, a.go, a.ge, 8 * besta, 0, T, m, e);
-        cp_reduce<W, K, false>(ln, T, m, e, bestF, jb, bestA);
-      }
-      else
+      int bestA[4], bestF, jb;
+      int edgeFx = 0;
+      if (G)
       {
         set_masks(r);
-        const int edgeFx = (r < W) ? a.go + (r + 1) * a.ge : SENT;
-        cp_update<W, K, true>(ln, a.go, a.ge, 8 * besta, edgeFx, T, m, e);
-        cp_reduce<W, K, true>(ln, T, m, e, bestF, jb, bestA);
+        edgeFx = a.go + (r + 1) * a.ge;                          // used in the first W rows only (set_masks: iWr)
       }
+      cp_update<W, K, G>(ln, vgo, vge, 8 * besta, edgeFx, T, m, e);
+      CP_TICK(2);                // row update
+      cp_reduce<W, K, G>(ln, T, m, e, bestF, jb, bestA);
+      CP_TICK(3);                // reductions
       if (bestF > high) { high = bestF; pos = r + jb - W; }      // ram_extend.c:1140-1150
       if (new_max) { thigh = high; tpos = pos; }                 // :1203-1207
       finish_column(bestA, contrib);
+      lookups(T);                // next column's table rows
     }
-    if (stopped || r == a.L - 1) break;
+    CP_TICK(4);                  // records, contributions, window slide, next lookups issued
+    if (stopped || r == a.L - 1) return true;
     publish(r, contrib);
+    CP_TICK(5);                  // wave sum, LDS atomics, barrier
+    return false;
+  };
+  // wave-uniform: every flank of the wave covers the whole band of rows r and r+1 (padding flanks: all-N stream, masked vote)
+  auto is_fast = [&](const int r) __attribute__((always_inline)) -> bool
+  {
+#ifdef CP_PROBE_NO_G
+    return true;
+#elif defined(CP_PROBE_NO_F)
+    return false;
+#else
+    return !live || __all(!active || ((bd.x - r <= 0) && (bd.y - r >= B)));
+#endif
+  };
+#ifdef RAMX_CP_TIMING
+  tlast = __builtin_amdgcn_s_memtime();
+#endif
+  for (int r = 0; r < a.L;)
+  {
+    bool end = false;
+    if (is_fast(r))
+    {
+      do { end = column(r, std::false_type{}); r++; } while (!end && r < a.L && is_fast(r));
+    }
+    else
+    {
+      end = column(r, std::true_type{});
+      r++;
+    }
+    if (end) break;
   }
+#ifdef RAMX_CP_TIMING
+  if (a.dbg != NULL && blockIdx.x == 0 && lane == 0)
+  {
+#pragma unroll
+    for (int k = 0; k < 8; k++) a.dbg[wave * 8 + k] = tsum[k];
+    if (wave == 0) a.dbg[16 * 8] = (unsigned long long)rows_done;
+  }
+#endif
   if (live && a.state_out != NULL && active)
   {
     static_for([&](auto ic) __attribute__((always_inline))
