@@ -63,7 +63,7 @@ static int cp_launch(hipStream_t st, int threads, int F, const CPArgs &a)
   else
   {
     if (threads > CpCfg<W, K>::MAXT) return RAMX_ERR_ARG;
-    hipLaunchKernelGGL((ramx_cp_family_kernel<W, K>), dim3(F), dim3(threads), 0, st, a);
+    hipLaunchKernelGGL((ramx_cp_kernel<W, K, false>), dim3(F), dim3(threads), 0, st, a);
     return hipGetLastError() == hipSuccess ? RAMX_OK : RAMX_ERR_HIP;
   }
 }
@@ -91,6 +91,75 @@ int ramx_cp_launch_families(hipStream_t st, int W, int K, int threads, int F, co
     case 20: return cp_launch_w<20>(st, K, threads, F, a);
     case 40: return cp_launch_w<40>(st, K, threads, F, a);
     case 80: return cp_launch_w<80>(st, K, threads, F, a);
+  }
+  return RAMX_ERR_UNSUPPORTED;
+}
+
+// ---- device-wide mode ----------------------------------------------------------------------------
+// One 512-thread workgroup per CU at most (the vote barrier wants few participants and the launch must be co-resident).
+// Lanes per flank: as many as keep the set within `cus` workgroups, but not more than a family of that size would get.
+int ramx_cp_device_plan(int W, int n, int cus, int *K, int *threads, int *blocks)
+{
+  *K = 0; *threads = 0; *blocks = 0;
+  if (n <= 0 || cus <= 0) return RAMX_OK;
+  const char *fk = getenv("RAMX_CP_K");
+  const int force = fk ? atoi(fk) : 0;
+  for (int k = 16; k >= 2; k >>= 1)
+  {
+    if (force >= 2 && k > force) continue;
+    int t = cp_max_threads(W, cp_cells(W, k));
+    if (t == 0) continue;
+    const char *ft = getenv("RAMX_CP_DEV_THREADS");  // tuning hook: workgroup size of the device-wide launch
+    if (ft && atoi(ft) >= 64 && atoi(ft) <= t && (atoi(ft) & 63) == 0) t = atoi(ft);
+    const int per = t / k;
+    const int nb = (n + per - 1) / per;
+    if (nb > cus) continue;
+    *K = k; *threads = t; *blocks = nb;
+    return RAMX_OK;
+  }
+  return RAMX_OK;
+}
+
+template <int W, int K>
+static int cp_launch_dev(hipStream_t st, int threads, int blocks, const CPArgs &a)
+{
+  if constexpr (CpCfg<W, K>::MAXT == 0) return RAMX_ERR_UNSUPPORTED;
+  else
+  {
+    if (threads > CpCfg<W, K>::MAXT) return RAMX_ERR_ARG;
+    int per_cu = 0, dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return RAMX_ERR_HIP;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ramx_cp_kernel<W, K, true>, threads, 0) != hipSuccess) return RAMX_ERR_HIP;
+    if (per_cu < 1 || blocks > cus) return RAMX_ERR_UNSUPPORTED;      // one workgroup per CU by design
+    CPArgs copy = a;
+    void *args[] = { (void *)&copy };
+    hipError_t e = hipLaunchCooperativeKernel((const void *)ramx_cp_kernel<W, K, true>, dim3(blocks), dim3(threads), args, 0, st);
+    return e == hipSuccess ? RAMX_OK : RAMX_ERR_HIP;
+  }
+}
+
+template <int W>
+static int cp_launch_dev_w(hipStream_t st, int K, int threads, int blocks, const CPArgs &a)
+{
+  switch (K)
+  {
+    case 16: return cp_launch_dev<W, 16>(st, threads, blocks, a);
+    case 8: return cp_launch_dev<W, 8>(st, threads, blocks, a);
+    case 4: return cp_launch_dev<W, 4>(st, threads, blocks, a);
+    case 2: return cp_launch_dev<W, 2>(st, threads, blocks, a);
+  }
+  return RAMX_ERR_UNSUPPORTED;
+}
+
+int ramx_cp_launch_device(hipStream_t st, int W, int K, int threads, int blocks, const CPArgs &a)
+{
+  if (blocks <= 0 || threads < 64 || threads > 1024 || (threads & 63)) return RAMX_ERR_ARG;
+  switch (W)
+  {
+    case 14: return cp_launch_dev_w<14>(st, K, threads, blocks, a);
+    case 20: return cp_launch_dev_w<20>(st, K, threads, blocks, a);
+    case 40: return cp_launch_dev_w<40>(st, K, threads, blocks, a);
+    case 80: return cp_launch_dev_w<80>(st, K, threads, blocks, a);
   }
   return RAMX_ERR_UNSUPPORTED;
 }

@@ -18,6 +18,11 @@ struct CPArgs
   int Np, KW, L, go, ge, cap, minimp, when_to_stop;
   int tab[RAMX_NCLASS][4];
   unsigned long long *dbg;      // -DRAMX_CP_TIMING builds only: [wave of block 0][8] phase sums in shader clocks
+  // device-wide mode (one flank set over the whole grid)
+  int Nx, nblocks;              // flanks that exist (the rest of [0, Np) is padding); workgroups of the launch
+  struct PShard *vote;          // [3][NSHARD] ticketed vote words (zeroed by the host before the launch)
+  unsigned *err;                // != 0: a bounded spin gave up
+  int4 *S;                      // optional: final rows in the lane-per-flank layout (ramx_dev_peek_state), else NULL
 };
 
 #define RAMX_CP_NCLASS 6
@@ -27,3 +32,7 @@ int ramx_cp_max_family(int W, int go, int ge, const int (&tab)[RAMX_NCLASS][4], 
 // class of a family of nx flanks (0 .. RAMX_CP_NCLASS-1): lanes per flank and workgroup size; -1 if too large
 int ramx_cp_class(int W, int nx, int *lanes_per_flank, int *threads);
 int ramx_cp_launch_families(hipStream_t st, int W, int lanes_per_flank, int threads, int n_families, const CPArgs &a);
+// Device-wide mode: lanes per flank and workgroup count for n flanks on `cus` compute units (one 512-thread workgroup per
+// CU at most), 0 lanes if the set does not fit or the width / scoring system is not supported (ramx_cp_max_family > 0).
+int ramx_cp_device_plan(int W, int n_flanks, int cus, int *lanes_per_flank, int *threads, int *blocks);
+int ramx_cp_launch_device(hipStream_t st, int W, int lanes_per_flank, int threads, int blocks, const CPArgs &a);

@@ -113,6 +113,7 @@ struct ramx_dev
   PeerBox *devbox;     // this rank's fine-grained device-memory box (exported over hipIpc)
   hipStream_t cls_stream[RAMX_NGROUP]; hipEvent_t cls_ready, cls_done[RAMX_NGROUP]; int cls_init;   // batch mode: one stream per workgroup shape
   int force_chain;   // RAMX_FORCE_CHAIN=1: always run the full candidate recurrence (test hook)
+  int cp_flanks_ok;    // begin_direction: every flank is empty or has t_lo <= 0 (what the cell-parallel kernels take)
   int2 *d_cpstate; size_t cap_cpstate; int cpstate_W, cpstate_n;   // RAMX_CP_PEEK=1: final rows of the cell-parallel kernel (tests)
 };
 
@@ -262,6 +263,10 @@ extern "C" int ramx_dev_begin_direction(ramx_dev *d, const ramx_flank *flanks, i
   HIPCHK(hipMemsetAsync(d->d_sums, 0, 3 * NSHARD * 4 * sizeof(long long), d->stream));
   HIPCHK(hipMemsetAsync(d->d_cons, 0, (size_t)p->L + 16, d->stream));
   HIPCHK(hipStreamSynchronize(d->stream));
+  // the cell-parallel kernels take flanks that are empty or start at or before the first base behind the core edge
+  d->cp_flanks_ok = 1;
+  for (int i = 0; i < Nx; i++)
+    if (flanks[i].t_lo > 0 && flanks[i].t_lo <= flanks[i].t_hi) { d->cp_flanks_ok = 0; break; }
   d->ready = 1;
   return RAMX_OK;
 }
@@ -909,6 +914,47 @@ extern "C" int ramx_dev_run_direction(ramx_dev *d, ramx_run_info *info)
   const bool multi = (d->comm != NULL && d->nranks > 1) || d->cb != NULL;
 
   auto slot = [&](int r) { return d->d_sums + (size_t)(((r % 3) + 3) % 3) * NSHARD * 4; };
+  int launches = 0, nsamp = 0, pending = -1, chk = 0, lanes = 1;
+  bool persistent = false;
+  // ---- cell-parallel route (single GPU): K lanes per flank, the whole direction in one cooperative launch of at most one
+  // workgroup per CU; boundary row and every column inside the kernel ---------------------------------------------------
+  if (!multi && d->cp_flanks_ok && !d->force_chain && L > 0 && d->Nx > 0 && getenv("RAMX_NO_PERSISTENT") == NULL &&
+      getenv("RAMX_NO_CP_DEVICE") == NULL && ramx_cp_max_family(a.W, a.go, a.ge, d->tab, L) > 0)
+  {
+    int dev = 0, cus = 0, k = 0, th = 0, nb = 0;
+    HIPCHK(hipGetDevice(&dev));
+    HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    const char *mx = getenv("RAMX_CP_DEVICE_MAXN");
+    if (mx == NULL || d->Nx <= atoi(mx)) ramx_cp_device_plan(a.W, d->Nx, cus, &k, &th, &nb);
+    if (k > 0)
+    {
+      CPArgs ca;
+      memset(&ca, 0, sizeof(ca));
+      ca.bases = d->d_bases; ca.bounds = d->d_bounds; ca.trim = d->d_trim; ca.ctl_out = d->d_ctl; ca.cons_out = d->d_cons;
+      ca.Np = d->Np; ca.KW = d->KW; ca.L = L; ca.go = a.go; ca.ge = a.ge; ca.cap = a.cap; ca.minimp = a.minimp; ca.when_to_stop = a.when_to_stop;
+      memcpy(ca.tab, d->tab, sizeof(ca.tab));
+      ca.Nx = d->Nx; ca.nblocks = nb; ca.vote = d->d_vote; ca.err = d->d_err; ca.S = d->d_state[0];
+      HIPCHK(hipMemsetAsync(d->d_vote, 0, 3 * NSHARD * sizeof(PShard), d->stream));
+      HIPCHK(hipMemsetAsync(d->d_err, 0, 64, d->stream));
+      HIPCHK(hipMemsetAsync(d->d_ctl, 0, 2 * sizeof(RamxCtl), d->stream));
+      HIPCHK(hipEventRecord(d->ev_begin, d->stream));
+      int crc = ramx_cp_launch_device(d->stream, a.W, k, th, nb, ca);
+      if (crc == RAMX_OK)
+      {
+        HIPCHK(hipEventRecord(d->ev_end, d->stream));
+        HIPCHK(hipStreamSynchronize(d->stream));
+        RamxCtl c0;
+        HIPCHK(hipMemcpy(&c0, d->d_ctl, sizeof(c0), hipMemcpyDeviceToHost));
+        if (c0.pad == 0) { persistent = true; lanes = k; launches = 1; }
+        else fprintf(stderr, "ramx: device-wide vote of the cell-parallel launch timed out (bounded spin); repeating the direction with "
+                             "per-column launches\n");
+      }
+      else if (crc != RAMX_ERR_UNSUPPORTED) { ramx_set_error("cell-parallel device launch failed (W %d, %d lanes per flank, %d workgroups)", a.W, k, nb); return crc; }
+    }
+  }
+  const bool cp_done = persistent;
+  if (!cp_done)
+  {
   HIPCHK(hipMemsetAsync(d->d_sums, 0, 3 * NSHARD * 4 * sizeof(long long), d->stream));
   HIPCHK(hipEventRecord(d->ev_begin, d->stream));
   // K(-1): boundary row + candidates of row 0
@@ -916,8 +962,6 @@ extern "C" int ramx_dev_run_direction(ramx_dev *d, ramx_run_info *info)
   a.sums_in = slot(0); a.sums_out = slot(0); a.sums_zero = slot(1); a.nshards_in = NSHARD;
   launch_column<true>(d, a);
   HIPCHK(hipGetLastError());
-  int launches = 0, nsamp = 0, pending = -1, chk = 0;
-  bool persistent = false;
   {
     // the in-place row buffer holds S(-1) after K(-1); d_ctl[1] holds the initial control block, the persistent
     // kernel writes its final one to d_ctl[0]
@@ -946,6 +990,26 @@ extern "C" int ramx_dev_run_direction(ramx_dev *d, ramx_run_info *info)
       launch_column<true>(d, a);
       HIPCHK(hipMemsetAsync(d->d_ctl, 0, sizeof(RamxCtl), d->stream));
     }
+  }
+  else if (persistent)
+  {
+    // single GPU: a barrier that timed out (bounded spin, e.g. a co-tenant holding CUs) is not fatal -- repeat the
+    // direction with the per-column launches, exactly as the multi-rank branch above does
+    HIPCHK(hipStreamSynchronize(d->stream));
+    RamxCtl c0;
+    HIPCHK(hipMemcpy(&c0, d->d_ctl, sizeof(c0), hipMemcpyDeviceToHost));
+    if (c0.pad != 0)
+    {
+      fprintf(stderr, "ramx: device-wide barrier of the persistent launch timed out (bounded spin); repeating the direction with "
+                      "per-column launches\n");
+      persistent = false;
+      HIPCHK(hipMemsetAsync(d->d_sums, 0, 3 * NSHARD * 4 * sizeof(long long), d->stream));
+      a.r = -1; a.S_in = d->d_state[0]; a.S_out = d->d_state[1]; a.ctl_in = d->d_ctl; a.ctl_out = d->d_ctl + 1;
+      a.sums_in = slot(0); a.sums_out = slot(0); a.sums_zero = slot(1); a.nshards_in = NSHARD;
+      launch_column<true>(d, a);
+      HIPCHK(hipMemsetAsync(d->d_ctl, 0, sizeof(RamxCtl), d->stream));
+    }
+  }
   }
   d->last_persistent = persistent ? 1 : 0;
   const int CHUNK = 64;
@@ -985,7 +1049,7 @@ extern "C" int ramx_dev_run_direction(ramx_dev *d, ramx_run_info *info)
       chk ^= 1;
     }
   }
-  HIPCHK(hipEventRecord(d->ev_end, d->stream));
+  if (!cp_done) HIPCHK(hipEventRecord(d->ev_end, d->stream));
   HIPCHK(hipStreamSynchronize(d->stream));
   RamxCtl h[2];
   HIPCHK(hipMemcpy(h, d->d_ctl, sizeof(h), hipMemcpyDeviceToHost));
@@ -1016,6 +1080,7 @@ extern "C" int ramx_dev_run_direction(ramx_dev *d, ramx_run_info *info)
     info->kernel_ms_avg = cnt ? acc / cnt : 0.0;
     info->kernel_samples = cnt;
     info->persistent = persistent ? 1 : 0;
+    info->lanes_per_flank = lanes;
   }
   return RAMX_OK;
 }

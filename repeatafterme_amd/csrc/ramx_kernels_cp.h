@@ -272,7 +272,12 @@ __device__ __forceinline__ void cp_reduce(const CpLane &ln, const int (&T)[CpCfg
 }
 
 // ------------------------------------------------------------------------------------------
-// one workgroup = one family, K lanes per flank
+// the kernel: K lanes per flank.
+//   DEV = false   one workgroup = one family (batch mode, seam 1 for families up to one workgroup): block-local vote
+//   DEV = true    one flank set spread over the grid (cooperative launch, one workgroup per CU): the per-column vote
+//                 goes through the sharded ticket words of the persistent kernel (ramx_kernels_resident.h: every
+//                 workgroup adds its four partial sums, tagged with an arrival ticket, into one of 32 shards; wave 0 of
+//                 every workgroup polls the shards of the column it is about to start).  Single GPU only.
 // ------------------------------------------------------------------------------------------
 #ifdef RAMX_CP_TIMING
 #define CP_TICK(k) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
@@ -281,8 +286,8 @@ __device__ __forceinline__ void cp_reduce(const CpLane &ln, const int (&T)[CpCfg
 #define CP_TICK(k) do { } while (0)
 #endif
 
-template <int W, int K>
-__global__ __launch_bounds__((CpCfg<W, K>::MAXT > 0 ? CpCfg<W, K>::MAXT : 64)) void ramx_cp_family_kernel(const CPArgs a)
+template <int W, int K, bool DEV>
+__global__ __launch_bounds__((CpCfg<W, K>::MAXT > 0 ? CpCfg<W, K>::MAXT : 64)) void ramx_cp_kernel(const CPArgs a)
 {
   typedef CpCfg<W, K> Cfg;
   constexpr int B = Cfg::B, C = Cfg::C, NA = Cfg::NA, NWL = Cfg::NWL, FPW = 64 / K;
@@ -291,18 +296,29 @@ __global__ __launch_bounds__((CpCfg<W, K>::MAXT > 0 ? CpCfg<W, K>::MAXT : 64)) v
   struct Smem
   {
     int tab[16];                                     // class -> {M[A][b] | M[C][b] | M[G][b] | M[T][b]} as four int8
-    unsigned long long vote[3][4];
+    unsigned long long vote[3][4];                   // DEV: [0..1] = this workgroup's partial sums (double buffered), [2] = the device-wide vote
+    int fail, pad[3];
   };
   __shared__ __attribute__((aligned(16))) Smem sm;
   // wave index through readfirstlane: `live` must be PROVABLY wave-uniform, or the band sits in a divergent region and
   // every column ends with one predicated copy per state register (phi of old and new row)
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const FamDesc fd = a.fam[blockIdx.x];
-  const int f = threadIdx.x / K;                     // flank inside the family
+  FamDesc fd;
+  if (DEV)
+  {
+    // the grid covers flanks [0, Np): workgroup b holds blockDim / K consecutive flanks
+    const int per = blockDim.x / K;
+    fd.tile0 = 0; fd.ntiles = 0; fd.id = 0;
+    fd.nx = a.Nx - blockIdx.x * per;                 // flanks (of this workgroup) that exist
+    fd.nx = fd.nx < 0 ? 0 : (fd.nx > per ? per : fd.nx);
+  }
+  else fd = a.fam[blockIdx.x];
+  const int f = threadIdx.x / K;                     // flank inside the family / workgroup
   const bool live = wave * FPW < fd.nx;              // wave-uniform: does this wave hold any flank?
   const bool active = f < fd.nx;
-  const int n = fd.tile0 * 64 + (live ? f : 0);
-  (void)lane;
+  const int n = DEV ? blockIdx.x * (blockDim.x / K) + (live ? f : 0) : fd.tile0 * 64 + (live ? f : 0);
+  const int my_shard_blocks = DEV ? (a.nblocks - (lane & (NSHARD - 1)) + NSHARD - 1) / NSHARD : 0;   // wave 0: blocks arriving on shard lane & 31
+  int failed = 0;
 
   if (threadIdx.x < 16)
   {
@@ -314,6 +330,7 @@ __global__ __launch_bounds__((CpCfg<W, K>::MAXT > 0 ? CpCfg<W, K>::MAXT : 64)) v
     sm.tab[cls] = (int)pk;
   }
   if (threadIdx.x < 12) sm.vote[threadIdx.x >> 2][threadIdx.x & 3] = 0ULL;
+  if (threadIdx.x == 0) sm.fail = 0;
   __syncthreads();
 
   CpLane ln;
@@ -405,8 +422,11 @@ __global__ __launch_bounds__((CpCfg<W, K>::MAXT > 0 ? CpCfg<W, K>::MAXT : 64)) v
       w[NWL] = a.bases[(size_t)(wn < a.KW ? wn : a.KW - 1) * a.Np + n];
     }
   };
-  // vote sets rotate: column r reads set r % 3, adds to set (r+1) % 3 and clears set (r+2) % 3 (last read at the top of
-  // column r-1, next added to during column r+1; the barrier at the end of every column separates the three uses)
+  // Block-local vote (DEV = false): three sets rotate -- column r reads set r % 3, adds to set (r+1) % 3 and clears set
+  // (r+2) % 3 (last read at the top of column r-1, next added to during column r+1; the barrier at the end of every
+  // column separates the three uses).
+  // Device-wide vote (DEV = true): the waves add into the workgroup's partial sums [(r+1) & 1]; after the barrier four
+  // threads forward them, with the arrival ticket, to this workgroup's shard of device set (r+1) % 3 and clear them.
   auto publish = [&](int r, unsigned (&contrib)[4]) __attribute__((always_inline))
   {
     if (live)
@@ -415,14 +435,69 @@ __global__ __launch_bounds__((CpCfg<W, K>::MAXT > 0 ? CpCfg<W, K>::MAXT : 64)) v
       if (lane == 0)
       {
 #pragma unroll
-        for (int c = 0; c < 4; c++) atomicAdd(&sm.vote[(r + 4) % 3][c], (unsigned long long)contrib[c]);
+        for (int c = 0; c < 4; c++) atomicAdd(&sm.vote[DEV ? ((r + 1) & 1) : (r + 4) % 3][c], (unsigned long long)contrib[c]);
       }
     }
     // LDS traffic only: the barrier must not wait for the global accesses in flight (the base word loaded for eight
     // columns ahead, the consensus byte) as __syncthreads() would
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (DEV)
+    {
+      if (blockIdx.x == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // workgroup 0: its clearing stores first
+      if (threadIdx.x < 4)
+      {
+        const unsigned long long t = sm.vote[(r + 1) & 1][threadIdx.x];
+        sm.vote[(r + 1) & 1][threadIdx.x] = 0ULL;    // next added to two columns (two barriers) from now
+        PShard *sh = a.vote + (size_t)((r + 4) % 3) * NSHARD + (blockIdx.x % NSHARD);
+        __hip_atomic_fetch_add(&sh->word[threadIdx.x], t + PRK_BIAS + PRK_TICKET, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
   };
-
+  // DEV: wave 0 waits until every workgroup's contribution to the vote of row r has arrived (bounded spin), folds the 32
+  // shards and leaves the four sums in sm.vote[2]; returns after the workgroup barrier.  Same protocol and encoding as
+  // ramx_persistent_kernel.
+  auto wait_vote = [&](int r) __attribute__((always_inline))
+  {
+    if (wave == 0)
+    {
+      const int sidx = lane & (NSHARD - 1), half = lane >> 5;
+      const unsigned long long *src = &a.vote[(size_t)(r % 3) * NSHARD + sidx].word[2 * half];
+      unsigned spins = 0;
+      bool done = my_shard_blocks <= 0;
+      unsigned long long x0 = 0, x1 = 0;
+      for (;;)
+      {
+        if (!done)
+        {
+          typedef unsigned v4u __attribute__((ext_vector_type(4)));
+          v4u q;
+          asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(q) : "v"(src) : "memory");
+          x0 = ((unsigned long long)q.y << 32) | q.x;
+          x1 = ((unsigned long long)q.w << 32) | q.z;
+          done = (x0 >> 54) >= (unsigned long long)my_shard_blocks && (x1 >> 54) >= (unsigned long long)my_shard_blocks;
+        }
+        if (__all(done)) break;
+        if (++spins > PRK_SPIN_LIMIT || ((spins & 1023u) == 0 && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0))
+        {
+          failed = 1;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      long long y0 = 0, y1 = 0;
+      if (my_shard_blocks > 0 && !failed)
+      {
+        y0 = (long long)(x0 & (PRK_TICKET - 1)) - (long long)(x0 >> 54) * (long long)PRK_BIAS;
+        y1 = (long long)(x1 & (PRK_TICKET - 1)) - (long long)(x1 >> 54) * (long long)PRK_BIAS;
+      }
+#pragma unroll
+      for (int mm = 16; mm >= 1; mm >>= 1) { y0 += __shfl_xor(y0, mm, 64); y1 += __shfl_xor(y1, mm, 64); }
+      if (lane == 0) { sm.vote[2][0] = (unsigned long long)y0; sm.vote[2][1] = (unsigned long long)y1; sm.fail = failed; }
+      if (lane == 32) { sm.vote[2][2] = (unsigned long long)y0; sm.vote[2][3] = (unsigned long long)y1; }
+      if (lane == 0 && failed) __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  };
   // The table rows of a column depend only on the base stream: they are fetched at the end of the previous column,
   // ahead of the vote exchange, so that their LDS latency never sits in front of the band.
   int T[C + 1];
@@ -459,6 +534,11 @@ __global__ __launch_bounds__((CpCfg<W, K>::MAXT > 0 ? CpCfg<W, K>::MAXT : 64)) v
   {
     constexpr bool G = decltype(gc)::value;
     CP_TICK(7);                  // barrier released .. loop top
+    if (DEV)
+    {
+      wait_vote(r);
+      if (__builtin_amdgcn_readfirstlane(sm.fail)) { failed = 1; return true; }
+    }
     // vote of row r: block-local (added during the previous column).  The sums are non-negative: they are compared
     // as (high, low) unsigned halves on the scalar unit (there is no 64-bit scalar compare; the compiler's choice for a
     // signed 64-bit compare is a chain of vector instructions)
@@ -467,7 +547,7 @@ __global__ __launch_bounds__((CpCfg<W, K>::MAXT > 0 ? CpCfg<W, K>::MAXT : 64)) v
 #pragma unroll
     for (int k = 0; k < 4; k++)
     {
-      const unsigned long long vv = sm.vote[r % 3][k];
+      const unsigned long long vv = sm.vote[DEV ? 2 : r % 3][k];
       const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(vv >> 32)), lo = (unsigned)__builtin_amdgcn_readfirstlane((int)vv);
       if (hi != 0 || lo > 2147483647u) ovf = 1;                  // the reference's int accumulator would have wrapped
       if (hi > chi || (hi == chi && lo > clo)) { chi = hi; clo = lo; besta = k; }   // ram_extend.c:1081-1085
@@ -481,8 +561,21 @@ __global__ __launch_bounds__((CpCfg<W, K>::MAXT > 0 ? CpCfg<W, K>::MAXT : 64)) v
     d2 = d2 < 0 ? -d2 : d2;
     stopped = d2 >= a.when_to_stop;                              // :1216
     rows_done = r + 1;
-    if (threadIdx.x == 0) a.cons_out[(size_t)fd.id * a.L + r] = (signed char)besta;
-    if (threadIdx.x < 4) sm.vote[(r + 2) % 3][threadIdx.x] = 0ULL;
+    if (!DEV)
+    {
+      if (threadIdx.x == 0) a.cons_out[(size_t)fd.id * a.L + r] = (signed char)besta;
+      if (threadIdx.x < 4) sm.vote[(r + 2) % 3][threadIdx.x] = 0ULL;
+    }
+    else if (blockIdx.x == 0)
+    {
+      if (threadIdx.x == 0) a.cons_out[r] = (signed char)besta;
+      if (threadIdx.x < NSHARD)     // workgroup 0 clears the device set of row r+2 (protocol: ramx_kernels_resident.h)
+      {
+        PShard *z = a.vote + (size_t)((r + 2) % 3) * NSHARD + threadIdx.x;
+#pragma unroll
+        for (int k = 0; k < 4; k++) __hip_atomic_store(&z->word[k], 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
     unsigned contrib[4] = { 0, 0, 0, 0 };
     CP_TICK(0);                  // vote read, stop rule
     if (live)
@@ -553,11 +646,28 @@ __global__ __launch_bounds__((CpCfg<W, K>::MAXT > 0 ? CpCfg<W, K>::MAXT : 64)) v
       if (ln.j0 + i < B) a.state_out[(size_t)n * B + ln.j0 + i] = make_int2(m[i], e[i]);
     }, std::make_integer_sequence<int, C>{});
   }
-  if (live && ln.pL0) a.trim[n] = make_int2(thigh, tpos);
-  if (threadIdx.x == 0)
+  if (DEV && live && a.S != NULL && n < a.Np)
+  {
+    // final rows in the layout of the lane-per-flank kernels (ramx_dev_peek_state): slot q of tile n / 64 holds cells
+    // 2q, 2q+1 as (m, e, m, e); the last slot holds cell 2W and (high, pos)
+    int *S = reinterpret_cast<int *>(a.S) + ((size_t)(n >> 6) * (W + 1) * 64 + (n & 63)) * 4;
+    static_for([&](auto ic) __attribute__((always_inline))
+    {
+      constexpr int i = decltype(ic)::value;
+      const int j = ln.j0 + i;
+      if (j < B)
+      {
+        int *p = S + (size_t)(j >> 1) * 64 * 4 + (j & 1) * 2;
+        p[0] = m[i]; p[1] = e[i];
+      }
+    }, std::make_integer_sequence<int, C>{});
+    if (ln.pL0) { int *p = S + (size_t)W * 64 * 4 + 2; p[0] = high; p[1] = pos; }
+  }
+  if (live && ln.pL0 && (!DEV || n < a.Np)) a.trim[n] = make_int2(thigh, tpos);
+  if (threadIdx.x == 0 && (!DEV || blockIdx.x == 0))
   {
     RamxCtl o;
-    o.max_ext = max_ext; o.max_row = max_row; o.stopped = stopped; o.rows_done = rows_done; o.overflow = ovf; o.besta = 0; o.pad = 0;
-    a.ctl_out[fd.id] = o;
+    o.max_ext = max_ext; o.max_row = max_row; o.stopped = stopped; o.rows_done = rows_done; o.overflow = ovf; o.besta = 0; o.pad = failed;
+    a.ctl_out[DEV ? 0 : fd.id] = o;
   }
 }

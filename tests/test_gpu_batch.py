@@ -13,6 +13,18 @@ from helpers import to_extend_params
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["cell-parallel where it applies", "lane per flank only"])
+def _route(request, monkeypatch):
+    """Families the cell-parallel kernel can take (W 14/20/40/80, non-positive penalties, up to 256 flanks) run K lanes
+    per flank; every test of this file runs a second time with that kernel switched off so that the lane-per-flank
+    family kernels (register-resident and streaming) keep their coverage."""
+    if request.param == "lane per flank only":
+        monkeypatch.setenv("RAMX_NO_CP", "1")
+    else:
+        monkeypatch.delenv("RAMX_NO_CP", raising=False)
+    yield request.param
+
+
 def _families(k):
     fams = []
     for i in range(k):
@@ -76,9 +88,10 @@ def test_batch_edge_cases_and_fallback():
     (40, "14p43g", dict(gapopen=3, gapextn=-4)),         # positive penalty: full candidate recurrence (CHAIN)
     (14, "25p43g", dict(gapopen=-20, gapextn=2)),
 ])
-def test_streaming_family_kernel_any_width_and_gap_sign(W, matrix, kw):
-    """Families the register-resident batch kernel cannot take run in the streaming family kernel (persistent == 2):
-    still one launch for all of them, each equal to its own oracle run."""
+def test_streaming_family_kernel_any_width_and_gap_sign(W, matrix, kw, _route):
+    """Families no register-resident kernel can take run in the streaming family kernel (persistent == 2): still one
+    launch for all of them, each equal to its own oracle run.  (W = 80 with the built-in penalties is register-resident
+    in the cell-parallel kernel: lanes_per_flank > 1, persistent == 1.)"""
     fams = _families(24)
     p = po.Params.named(matrix, bandwidth=W, L=160, when_to_stop=25, **kw)
     got_c = [fs.cores.copy() for fs in fams]
@@ -94,7 +107,10 @@ def test_streaming_family_kernel_any_width_and_gap_sign(W, matrix, kw):
         assert np.array_equal(got_m[i], m), (W, i)
         assert np.array_equal(got_c[i].left_len, c.left_len) and np.array_equal(got_c[i].right_len, c.right_len), (W, i)
         assert np.array_equal(got_c[i].score, c.score), (W, i)
-        assert ir[i].persistent == 2 and il[i].persistent == 2
+        if W == 80 and not kw and _route != "lane per flank only" and ir[i].lanes_per_flank > 1:
+            assert ir[i].persistent == 1
+        else:
+            assert ir[i].persistent == 2 and il[i].persistent == 2
 
 
 @pytest.mark.parametrize("maxn", [20, 64, 100, 200, 400])

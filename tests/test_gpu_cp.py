@@ -19,8 +19,8 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(autouse=True)
 def _cp_on(monkeypatch):
-    monkeypatch.delenv("RAMX_NO_CP", raising=False)
-    monkeypatch.delenv("RAMX_CP_K", raising=False)
+    for k in ("RAMX_NO_CP", "RAMX_CP_K", "RAMX_NO_CP_DEVICE", "RAMX_NO_FAMILY_ROUTE", "RAMX_NO_PERSISTENT"):
+        monkeypatch.delenv(k, raising=False)
     yield
 
 
@@ -164,3 +164,49 @@ def test_cp_scoring_bounds_fall_back(monkeypatch):
     got = run_both_directions(gpu_extend, fs.cores, fs.sequence, base)
     assert_same_result(ref[0], ref[1], ref[2:], got[0], got[1], got[2:], "NO_CP")
     assert got[2].lanes_per_flank == 1
+
+
+# ---- device-wide mode: one flank set over many workgroups, vote through the ticketed shard words ----------------
+
+@pytest.mark.parametrize("W,n,K,matrix", [(40, 1000, 16, "14p43g"), (40, 5000, 16, "14p43g"), (14, 3000, 16, "20p43g"),
+                                          (80, 2500, 16, "20p43g"), (20, 20000, 4, "repeatscout"), (40, 700, 16, "25p43g")])
+def test_cp_device_wide_equals_oracle(W, n, K, matrix):
+    """Flank sets above one workgroup (BASELINE config 2's N = 1,000 among them): the cell-parallel kernel in device-wide
+    mode, both directions, mixed strands and N runs, against the oracle."""
+    L = 150 if n <= 5000 else 60
+    fs = synth_family(n, L, W, K=100 if n <= 5000 else 40, seed=50 + W, both_sides=True, minus_frac=0.3, n_run_frac=0.1,
+                      core_len=(2 * W + 2 if n != 5000 else 9))
+    p = po.Params.named(matrix, bandwidth=W, L=L, when_to_stop=30)
+    a = run_both_directions(oracle_extend, fs.cores, fs.sequence, p)
+    b = run_both_directions(gpu_extend, fs.cores, fs.sequence, p)
+    assert_same_result(a[0], a[1], a[2:], b[0], b[1], b[2:], f"W={W} n={n}")
+    assert (a[2].rows_executed, a[3].rows_executed) == (b[2].rows_executed, b[3].rows_executed)
+    assert b[2].persistent == 1 and b[2].lanes_per_flank == K and b[3].lanes_per_flank == K
+
+
+@pytest.mark.parametrize("K", [2, 4, 8, 16])
+def test_cp_device_wide_small_sets_every_shape(K, monkeypatch):
+    """With the one-workgroup route off even a tiny set runs device-wide: adversarial ragged sets (masked path, flanks
+    that end early, empty flanks) through every lanes-per-flank shape."""
+    monkeypatch.setenv("RAMX_NO_FAMILY_ROUTE", "1")
+    monkeypatch.setenv("RAMX_CP_K", str(K))
+    for seed in (300, 301, 302):
+        fs = synth_adversarial(seed, n_windows=30, L=110, W=20, K=70, lowercase=(seed % 2 == 0))
+        p = po.Params.named("14p43g" if seed % 2 else "repeatscout", bandwidth=20, L=110, when_to_stop=25)
+        a = run_both_directions(oracle_extend, fs.cores, fs.sequence, p)
+        b = run_both_directions(gpu_extend, fs.cores, fs.sequence, p)
+        assert_same_result(a[0], a[1], a[2:], b[0], b[1], b[2:], f"seed={seed} K={K}")
+        assert (a[2].rows_executed, a[3].rows_executed) == (b[2].rows_executed, b[3].rows_executed)
+
+
+def test_cp_device_wide_config2_full():
+    """BASELINE config 2 in full: N = 1,000 flanks x L = 2,000 bp, bandwidth 40, 14p43g, right extension, 1,600 columns."""
+    fs = synth_family(1000, 2000, 40, K=1500, seed=1)
+    p = po.Params.named("14p43g", bandwidth=40, L=2000)
+    c1, c2 = fs.cores.copy(), fs.cores.copy()
+    m1, m2 = new_master(2000), new_master(2000)
+    a = po.oracle_extend(1, c1, fs.sequence, m1, p)
+    b = gpu_extend(1, c2, fs.sequence, m2, p)
+    assert (a.ret, a.rows_executed) == (b.ret, b.rows_executed) == (1500, 1600)
+    assert np.array_equal(m1, m2) and np.array_equal(c1.right_len, c2.right_len) and np.array_equal(c1.score, c2.score)
+    assert b.lanes_per_flank == 16 and b.persistent == 1

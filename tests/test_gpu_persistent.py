@@ -14,15 +14,18 @@ from helpers import assert_same_result, gpu_extend, oracle_extend, run_both_dire
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["one-workgroup route", "device-wide only"])
+@pytest.fixture(autouse=True, params=["one-workgroup route", "device-wide cell-parallel", "device-wide lane-per-flank"])
 def _small_family_route(request, monkeypatch):
     """Seam 1 runs a family of up to 512 extendable cores as a batch of one (block-local vote); every test of this
-    file runs a second time with that route switched off, so the device-wide persistent kernel keeps its coverage at
+    file runs again with that route switched off, once through the device-wide cell-parallel kernel (K lanes per
+    flank) and once through the device-wide lane-per-flank persistent kernel, so that all three keep their coverage at
     small sizes."""
-    if request.param == "device-wide only":
+    monkeypatch.delenv("RAMX_NO_FAMILY_ROUTE", raising=False)
+    monkeypatch.delenv("RAMX_NO_CP_DEVICE", raising=False)
+    if request.param != "one-workgroup route":
         monkeypatch.setenv("RAMX_NO_FAMILY_ROUTE", "1")
-    else:
-        monkeypatch.delenv("RAMX_NO_FAMILY_ROUTE", raising=False)
+    if request.param == "device-wide lane-per-flank":
+        monkeypatch.setenv("RAMX_NO_CP_DEVICE", "1")
     yield
 
 
