@@ -1,13 +1,14 @@
 #!/usr/bin/env python3
 """bench.py -- RAMExtend extension loop on MI355X: flank-bp aligned / s (= extension columns/s x flanks).
 
-Workload (BASELINE.json configs[2] / configs[3]): synthetic N = 100,000 flanks per GPU x L = 10,000 bp,
+Workload (BASELINE.json configs[2] / configs[3]): synthetic N = 100,000 flanks x L = 10,000 bp,
 bandwidth 40, matrix 14p43g, shared 1,500 bp ancestor at 14 % divergence, -stopafter L so that all L
 columns of the right extension are executed.  One "step" = one full pass of the extension loop
-(ramx_dev_run_direction: L column launches) over the flank set already resident in HBM.
+(ramx_dev_run_direction) over the flank set already resident in HBM.
 
-N > 1: one process per GPU (torch.distributed launcher), flanks sharded over ranks (weak scaling:
-100,000 flanks per rank), one 4 x int64 RCCL all-reduce per column inside libramx.
+N > 1: one process per GPU (torch.distributed launcher), flanks sharded over ranks.  Default is STRONG scaling --
+BASELINE configs[3]: the same 100,000 flanks split over the ranks, one vote exchange per column; `--scaling weak`
+gives every rank its own 100,000 flanks.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
 """
@@ -32,6 +33,12 @@ from repeatafterme_amd.scoring import get_matrix  # noqa: E402
 from repeatafterme_amd.synth import synth_family  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+# VALU issue: 256 CUs x 4 SIMDs, 2.4 GHz, a wave64 VALU instruction every 2 cycles per SIMD (MI355X_MICROARCH.md,
+# "Wave scheduling" / cycle constants).  tools/microbench/valu_rate.hip shows that only part of the integer VALU set
+# reaches that rate on gfx950 (profiles/r02_valu_rate.log); the roofline keeps the guide's 2-cycle peak and reports the
+# instruction-mix-weighted figure next to it.
+N_SIMD, CLOCK_GHZ, GUIDE_ISSUE_CYCLES = 1024, 2.4, 2.0
+VALU_PEAK_GINST = N_SIMD * CLOCK_GHZ / GUIDE_ISSUE_CYCLES
 
 
 def algorithmic_bytes_per_flank_column(W: int) -> float:
@@ -78,7 +85,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--flanks", type=int, default=100000, help="flanks per GPU")
+    ap.add_argument("--flanks", type=int, default=100000, help="flanks (total under strong scaling, per GPU under weak scaling)")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="N > 1: strong = the --flanks set is split over the ranks (BASELINE configs[3]); weak = --flanks per rank")
+    ap.add_argument("--no-seam1", action="store_true", help="skip the seam-1 (ramx_extend_flat, host buffers) timing")
     ap.add_argument("--L", type=int, default=10000)
     ap.add_argument("--bandwidth", type=int, default=40)
     ap.add_argument("--cpu-flanks", type=int, default=20000)
@@ -107,12 +117,21 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    W, L, N = args.bandwidth, args.L, args.flanks
+    W, L = args.bandwidth, args.L
+    strong = world > 1 and args.scaling == "strong"
+    if strong:
+        base, rem = divmod(args.flanks, world)
+        N = base + (1 if rank < rem else 0)          # this rank's shard of the fixed flank set
+        total_flanks = args.flanks
+    else:
+        N = args.flanks
+        total_flanks = N * world
     mat, go, ge = get_matrix("14p43g")
     p = ExtendParams(bandwidth=W, cappenalty=-90, minimprovement=27, L=L, when_to_stop=L, l=1,
                      gapopen=go, gapextn=ge, matrix=mat, matrix_name="14p43g")
     t0 = time.time()
-    fs = synth_family(N, L, W, K=1500, seed=1 + rank)   # each rank: its own shard of the family
+    # strong scaling: every rank generates its own part of ONE family (same ancestor); weak: one family per rank
+    fs = synth_family(N, L, W, K=1500, seed=1, shard=rank) if strong else synth_family(N, L, W, K=1500, seed=1 + rank)
     t_gen = time.time() - t0
 
     ndev = max(_lib.lib().ramx_device_count(), 1)
@@ -194,7 +213,6 @@ def main():
         raise SystemExit(f"bench: results of the timed passes differ from the warm-up pass ({digest0} vs {digest1})")
 
     cols = sum(i.rows_executed for i in infos)
-    total_flanks = N * world
     value = cols * total_flanks / dt
     # average launch duration of the dominant kernel, measured live with HIP events on libramx's own stream over
     # the timed region (ev_begin .. ev_end bracket the column loop inside ramx_dev_run_direction) / launches.
@@ -204,9 +222,10 @@ def main():
     loop_ms = float(sum(i.loop_ms for i in infos))
     persistent = all(i.persistent for i in infos)
     per_col_bytes = algorithmic_bytes_per_flank_column(W) * N          # one column over this GPU's flanks
+    lanes = infos[0].lanes_per_flank if infos else 1
     if persistent:
         # ONE launch per step processes N flanks x L columns; its duration is the event-timed loop
-        kernel = f"ramx_persistent_kernel<{W}>"
+        kernel = f"ramx_persistent_kernel<{W}>" if lanes == 1 else f"ramx_cp_kernel<{W},{lanes},device-wide>"
         n_launch = len(infos)
         kavg_ms = loop_ms / n_launch
         abytes = per_col_bytes * rows / n_launch
@@ -215,40 +234,87 @@ def main():
         n_launch = rows
         kavg_ms = loop_ms / max(rows, 1)
         abytes = per_col_bytes
-    achieved = abytes / (kavg_ms * 1e-3) / 1e9 if kavg_ms > 0 else 0.0
+    alg_gbps = abytes / (kavg_ms * 1e-3) / 1e9 if kavg_ms > 0 else 0.0
+    us_col = loop_ms * 1e3 / max(rows, 1)
+    # PMC figures (profiles/pmc_summary.json) are valid only for the configuration they were collected on
     traffic = None
     valu = None
+    insts_per_col = None
     pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
-    if os.path.exists(pmc):
+    if os.path.exists(pmc) and world == 1:
         try:
-            ent = json.load(open(pmc)).get("persistent" if persistent else "column", {})
-            per_col = ent.get("hbm_bytes_per_column")
-            traffic = per_col * rows / n_launch if (per_col is not None and persistent) else per_col
-            fit = json.load(open(pmc)).get("persistent_fit")
-            if persistent and fit:
-                # two PMC launches of different length (tools/pmc_traffic_fit.sh): rows in and out once per launch +
-                # the base stream per column
-                traffic = fit["fixed_bytes_per_launch"] + fit["bytes_per_column"] * rows / n_launch
-            # what actually bounds the persistent kernel: VALU issue.  Instructions per column from the same PMC pass
-            # (SQ_INSTS_VALU over the profiled launch's columns), time per column measured live; a wave64 VALU
-            # instruction occupies its SIMD for 4 cycles, 1,024 SIMDs at the 2.4 GHz peak engine clock.
-            cnt = ent.get("avg_per_dispatch", {})
-            if persistent and per_col and cnt.get("SQ_INSTS_VALU") and ent.get("hbm_bytes_per_launch"):
-                cols_prof = ent["hbm_bytes_per_launch"] / per_col
-                valu_per_col = cnt["SQ_INSTS_VALU"] / cols_prof
-                us_col = loop_ms * 1e3 / max(rows, 1)
-                valu = {"insts_per_column": valu_per_col,
-                        "issue_frac_whole_chip": valu_per_col * 4 / (1024 * 2.4e3 * us_col),
-                        "note": "secondary roof: share of all VALU issue slots (256 CUs) used over the whole column, "
-                                "barrier wait included; 196 of 256 CUs hold workgroups at N = 100,000"}
+            doc = json.load(open(pmc))
+            ent = doc.get("persistent" if persistent else "column", {})
+            cfg = doc.get("config", {"flanks": 100000, "bandwidth": 40})
+            if cfg.get("flanks") == N and cfg.get("bandwidth") == W and lanes == 1:
+                per_col = ent.get("hbm_bytes_per_column")
+                fit = doc.get("persistent_fit")
+                if persistent and fit:
+                    # two PMC launches of different length (tools/pmc_traffic_fit.sh): rows in and out once per launch +
+                    # the base stream per column
+                    traffic = fit["fixed_bytes_per_launch"] + fit["bytes_per_column"] * rows / n_launch
+                elif per_col is not None:
+                    traffic = per_col * rows / n_launch if persistent else per_col
+                cnt = ent.get("avg_per_dispatch", {})
+                cols_prof = ent.get("columns_per_launch") or (ent["hbm_bytes_per_launch"] / ent["hbm_bytes_per_column"] if ent.get("hbm_bytes_per_column") else None)
+                if cnt.get("SQ_INSTS_VALU") and cols_prof:
+                    insts_per_col = cnt["SQ_INSTS_VALU"] / (cols_prof if persistent else 1.0)
         except Exception:
             traffic = None
+    if insts_per_col:
+        ginst = insts_per_col / (us_col * 1e-6) / 1e9           # wave64 VALU instructions per second, whole chip
+        mix = None
+        try:
+            mix = json.load(open(os.path.join(ROOT, "profiles", "r02_valu_mix_persistent.json")))
+        except Exception:
+            pass
+        valu = {"insts_per_column": insts_per_col, "G_wave_inst_per_sec": ginst,
+                "peak_guide_2cycle": VALU_PEAK_GINST, "frac_guide_2cycle": ginst / VALU_PEAK_GINST}
+        if mix and persistent:
+            # instruction-mix-weighted issue cost of the band (static mix of the hot blocks x measured ticks per opcode class)
+            tpi = mix["hot_blocks_ticks_per_valu"]
+            valu["measured_ticks_per_inst"] = tpi
+            valu["frac_at_measured_issue_cost"] = insts_per_col * tpi / (N_SIMD * CLOCK_GHZ * 1e3 * us_col)
+            valu["note"] = ("only v_add/sub/and/or/mov (VGPR operands) issue every 2 cycles on gfx950; v_max3, SDWA, DPP, v_lshl_or, "
+                            "v_cndmask take 4 (profiles/r02_valu_rate.log): at the kernel's own mix the chip's issue slots are this "
+                            "fraction busy over the whole column, barrier wait and the 60 CUs without a workgroup included")
+        roof = {"bound": "valu", "achieved": ginst, "peak": VALU_PEAK_GINST, "unit": "G wave64-inst/s", "frac": ginst / VALU_PEAK_GINST}
+    else:
+        # no instruction count for this configuration: report the HBM figure of SURVEY 8(d) only
+        roof = {"bound": "hbm", "achieved": (traffic / (kavg_ms * 1e-3) / 1e9) if (traffic and kavg_ms > 0) else alg_gbps,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None}
+        roof["frac"] = roof["achieved"] / HBM_PEAK_GBS
+    roof.update({"traffic": traffic, "kernel": kernel, "kernel_avg_us": kavg_ms * 1e3, "launches_timed": n_launch, "us_per_column": us_col,
+                 "valu": valu,
+                 "hbm": {"algorithmic_bytes_per_flank_column": algorithmic_bytes_per_flank_column(W),
+                         "algorithmic_bytes_per_launch": abytes, "algorithmic_GBps": alg_gbps,
+                         "algorithmic_over_peak": alg_gbps / HBM_PEAK_GBS,
+                         "measured_traffic_GBps": (traffic / (kavg_ms * 1e-3) / 1e9) if (traffic and kavg_ms > 0) else None,
+                         "note": ("SURVEY 8(d) bytes that are NOT moved: the rows stay in registers / LDS for the whole launch, so the "
+                                  "algorithmic rate may exceed the 8 TB/s peak; `traffic` is what the PMC counters saw")
+                                 if persistent else "streaming kernel: rows read once and written once per column"}})
+
+    # ---- outside the timed region: seam 1 (host buffers in, host results out) on the same set ----------------------
+    seam1 = None
+    if world == 1 and not args.no_seam1:
+        from repeatafterme_amd.datamodel import new_master
+        from repeatafterme_amd.extend import extend_alignment
+        c1 = fs.cores.copy(); m1 = new_master(L)
+        t0 = time.perf_counter(); r_right = extend_alignment(1, c1, fs.sequence, m1, p); t_r = time.perf_counter() - t0
+        t0 = time.perf_counter(); r_left = extend_alignment(0, c1, fs.sequence, m1, p); t_l = time.perf_counter() - t0
+        s_cols = r_right.rows_executed + r_left.rows_executed
+        seam1 = {"what": "ramx_extend_flat right then left, host arrays in / results out: flatten + 1-byte library upload + pack + loop + download",
+                 "ms_right": t_r * 1e3, "ms_left": t_l * 1e3, "columns": s_cols, "columns_per_sec": s_cols / (t_r + t_l),
+                 "flank_bp_per_sec": (r_right.rows_executed * r_right.n_extendable + r_left.rows_executed * r_left.n_extendable) / (t_r + t_l),
+                 "loop_ms_right": r_right.loop_ms, "prep_ms_right": r_right.prep_ms}
     out = {
         "metric": "flank_bp_aligned_per_sec (extension columns/s x flanks)", "value": value, "unit": "flank-bp/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-        "config": {"workload": f"synthetic N={N} flanks/GPU x L={L} bp, bandwidth={W}, matrix 14p43g, "
-                               f"K=1500 @14% divergence, right extension, stopafter=L (all L columns)",
+        "higher_is_better": True, "scaling": ("strong" if strong else "weak"), "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+        "config": {"workload": (f"synthetic N={total_flanks} flanks" + (f" split over {world} GPUs" if strong else (" per GPU" if world > 1 else ""))
+                                + f" x L={L} bp, bandwidth={W}, matrix 14p43g, "
+                                f"K=1500 @14% divergence, right extension, stopafter=L (all L columns)"),
+                   "flanks_this_rank": N,
                    "flanks_total": total_flanks, "columns_per_step": cols // max(args.steps, 1),
                    "parallelism": (f"flank-sharded x{world}, per-column vote "
                                    + (("exchanged inside the persistent kernels (mailboxes in "
@@ -258,21 +324,27 @@ def main():
         "columns_per_sec": cols / dt,
         "checks": {"result_sha1": digest1, "same_as_warmup_pass": bool(digest0 is not None)},
         "cell_updates_per_sec": cols / dt * total_flanks * (2 * W + 1) * 4,
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": kernel, "kernel_avg_us": kavg_ms * 1e3, "launches_timed": n_launch,
-                     "us_per_column": loop_ms * 1e3 / max(rows, 1),
-                     "algorithmic_bytes_per_flank_column": algorithmic_bytes_per_flank_column(W),
-                     "algorithmic_bytes_per_launch": abytes, "valu": valu,
-                     "note": ("rows stay in registers/LDS for the whole launch: HBM traffic is far below the algorithmic "
-                              "bytes, so achieved exceeds the HBM peak; the kernel is VALU/barrier bound (DESIGN.md 4.2)")
-                             if persistent else "streaming kernel: one launch per column"},
+        "roofline": roof,
+        "seam1": seam1,
         "setup": {"synth_s": t_gen, "upload_pack_s": t_upload},
     }
     if rank == 0 and world == 1 and not args.no_cpu:
         cb, m_cpu, sub = cpu_baseline(fs, p, min(args.cpu_flanks, N), args.cpu_cols)
         out["cpu_baseline"] = cb
         out["gpu_over_cpu"] = value / cb["value"]
+        # the same sample on the GPU (outside every timed region): consensus, lengths and scores must equal the CPU result
+        from repeatafterme_amd.datamodel import new_master
+        from repeatafterme_amd.extend import extend_alignment
+        g = fs.cores.subset(slice(0, min(args.cpu_flanks, N)))
+        pg = ExtendParams(bandwidth=W, cappenalty=p.cappenalty, minimprovement=p.minimprovement, L=args.cpu_cols,
+                          when_to_stop=args.cpu_cols, l=1, gapopen=go, gapextn=ge, matrix=mat, matrix_name="14p43g")
+        m_gpu = new_master(args.cpu_cols)
+        hi = int(g.upper.max()) + 1
+        extend_alignment(1, g, np.ascontiguousarray(fs.sequence[:hi]), m_gpu, pg)
+        same = bool(np.array_equal(m_gpu, m_cpu) and np.array_equal(g.right_len, sub.right_len) and np.array_equal(g.score, sub.score))
+        out["checks"]["gpu_equals_cpu_on_baseline_sample"] = same
+        if not same:
+            raise SystemExit("bench: the GPU result on the cpu_baseline sample differs from the CPU result")
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:

@@ -173,9 +173,17 @@ __device__ __forceinline__ void fast_tabs_winner(FastTabs &ft, const int *tab_be
 // (the vote clamps at 0, ram_extend.c:1042) and their keys below every positive score (the best cell only matters when
 // it beats high >= 0): five extra VALU per cell instead of the general band's separate formulation.
 template <int W, int BLOCK, bool MASKHI>
-__device__ __forceinline__ void prk_band_fast(const int go, const int ge, const FastTabs &ft, short *sD, const int r, const int jhi,
+__device__ __forceinline__ void prk_band_fast(const int go_, const int ge_, const FastTabs &ft, short *sD, const int r, const int jhi,
                                               const unsigned (&w)[(2 * W + 1 + 8) / 8 + 2], int (&M)[2 * W + 1], LaneDP &D)
 {
+#ifdef RAMX_VGPR_GOGE
+  // v_add_u32 with two VGPR operands issues at twice the rate of one with an SGPR operand on gfx950
+  // (tools/microbench/valu_rate.hip); the empty asm keeps the copies in vector registers
+  int go = go_, ge = ge_;
+  asm volatile("" : "+v"(go), "+v"(ge));
+#else
+  const int go = go_, ge = ge_;
+#endif
   constexpr int B = 2 * W + 1, NG = (B + 15) / 16;
   const int ph4 = 4 * ((r + 8) & 7);
   const unsigned mask_f0 = 0xf0u;

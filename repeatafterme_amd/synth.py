@@ -61,11 +61,15 @@ def _flank_block(rng, anc, m, F, div):
 
 def synth_family(n: int, L: int, W: int, K: int = 1500, seed: int = 1, div: float = 0.14,
                  both_sides: bool = False, minus_frac: float = 0.0, n_run_frac: float = 0.0,
-                 core_len: int = 10, pad: int = 20, batch: int = 8192) -> FlankSet:
+                 core_len: int = 10, pad: int = 20, batch: int = 8192, shard: int = 0) -> FlankSet:
+    """``shard`` > 0: same ancestor and core as shard 0 (they come from ``seed`` alone), independent copies -- the
+    ranks of a sharded run each generate their own part of ONE family."""
     rng = np.random.default_rng(seed)
     anc_r = rng.integers(0, 4, size=K, dtype=np.int8)
     anc_l = rng.integers(0, 4, size=K, dtype=np.int8)
     core = rng.integers(0, 4, size=core_len, dtype=np.int8)
+    if shard:
+        rng = np.random.default_rng([seed, shard])
     F = L + W + pad
     FL = F if both_sides else 0
     win = FL + core_len + F

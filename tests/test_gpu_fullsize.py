@@ -19,18 +19,39 @@ def family():
     return synth_family(N, L, W, K=K, seed=1)
 
 
-def test_full_width_prefix_bit_exact_vs_oracle(family):
-    """All 100,000 flanks, first 24 columns: int32-exact column sums drive the same consensus, lengths, scores."""
-    fs = family
-    p = po.Params.named("14p43g", bandwidth=W, L=24, when_to_stop=24)
-    c1, c2 = fs.cores.copy(), fs.cores.copy()
-    m1, m2 = new_master(24), new_master(24)
+PREFIX = 128      # > 2W + 1: rows >= W run the steady-state band (sentinel fills, far-end-masked variant) at the bench's own shape
+
+
+def _prefix_vs_oracle(fs, cores, tag):
+    p = po.Params.named("14p43g", bandwidth=W, L=PREFIX, when_to_stop=PREFIX)
+    c1, c2 = cores.copy(), cores.copy()
+    m1, m2 = new_master(PREFIX), new_master(PREFIX)
     a = po.oracle_extend(1, c1, fs.sequence, m1, p, trace=True)
     b = gpu_extend(1, c2, fs.sequence, m2, p)
-    assert a.ret == b.ret and a.rows_executed == b.rows_executed == 24
-    assert np.array_equal(m1, m2)
-    assert np.array_equal(c1.right_len, c2.right_len) and np.array_equal(c1.score, c2.score)
+    assert a.ret == b.ret and a.rows_executed == b.rows_executed == PREFIX, tag
+    assert np.array_equal(m1, m2), tag
+    assert np.array_equal(c1.right_len, c2.right_len) and np.array_equal(c1.score, c2.score), tag
     assert int(np.abs(a.col_sums).max()) < 2 ** 31 and b.overflow32 == 0
+    assert b.persistent == 1 and b.lanes_per_flank == 1      # 196 workgroups x 512 lanes: the benchmarked kernel and shape
+    return b
+
+
+def test_full_width_prefix_bit_exact_vs_oracle(family):
+    """All 100,000 flanks, first 128 columns (the band is 81 cells wide: rows 40.. are the steady state of the bench):
+    int32-exact column sums drive the same consensus, lengths, scores."""
+    _prefix_vs_oracle(family, family.cores, "full-length flanks")
+
+
+def test_full_width_prefix_with_early_ending_flanks(family):
+    """The same 100,000 flanks with 2 % of them ending 0..160 bp behind the core: their waves leave the in-bounds fast band
+    for the far-end-masked variant (and the general band while r < W) while the other 1,500 waves stay on the fast
+    band -- mixed variants at the bench's shape, every output against the oracle."""
+    fs = family
+    cores = fs.cores.copy()
+    rng = np.random.default_rng(11)
+    short = np.nonzero(rng.random(N) < 0.02)[0]
+    cores.upper[short] = cores.right_pos[short] + rng.integers(0, 160, size=len(short))
+    _prefix_vs_oracle(fs, cores, "2 % early-ending flanks")
 
 
 def test_full_run_properties(family):
