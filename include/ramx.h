@@ -140,6 +140,12 @@ typedef struct ramx_run_info
 int ramx_extend_flat(int direction, ramx_flat_cores *cores, const int8_t *sequence, uint64_t seq_len,
                      int8_t *master, const ramx_params *p, ramx_run_info *info);
 
+/* Seam 1 keeps the library on the device between calls, keyed on (pointer, length, 64-bit content fingerprint), so
+ * the second direction does not upload it again; libraries above 64 MiB are uploaded on every call instead of being
+ * fingerprinted.  The reference has no such state (ram_extend.c reads seqLib->sequence on every call): a caller who
+ * wants to be explicit can drop the device copy with this call. */
+void ramx_invalidate_library(void);
+
 /* ------------------------------------------------------------------------------------------
  * Seam 2: thin device API (one ramx_dev per GPU / per process rank)
  * ------------------------------------------------------------------------------------------ */

@@ -534,6 +534,7 @@ static int prk_run(ramx_dev *d, const KArgs &a, int L, bool *used)
     can = !cannot;
   }
   if (!can) return RAMX_OK;
+  *used = true;        // agreed (multi-rank: by all ranks): from here on the caller handles a local failure collectively
   PArgs pa;
   memset(&pa, 0, sizeof(pa));
   pa.S = d->d_state[0]; pa.bases = d->d_bases; pa.bounds = d->d_bounds; pa.trim = d->d_trim;
@@ -545,29 +546,39 @@ static int prk_run(ramx_dev *d, const KArgs &a, int L, bool *used)
   {
     pa.nranks = d->nranks; pa.rank = d->rank; pa.peers = (PeerBox *const *)d->d_peer; pa.box = d->xbox;
     pa.mirror = NULL;
-    if (d->hostbox_host)
+    // Rank-local steps first, WITHOUT leaving on an error: the collective below is executed by every rank in any case
+    // (a rank that skipped it would pair its next collective with this one on the other ranks).
+    auto local_prep = [&]() -> int
     {
-      if (!d->hostbox_mirror) HIPCHK(hipMalloc((void **)&d->hostbox_mirror, sizeof(PeerBox)));
-      HIPCHK(hipMemsetAsync(d->hostbox_mirror, 0, sizeof(PeerBox), d->stream));
-      pa.mirror = d->hostbox_mirror;
-    }
-    // my box is cleared BEFORE the collective below, which no remote launch can get past without my taking part:
-    // nobody writes a word of this run into it too early, and nothing of the last run survives
-    if (d->hostbox_host)
-    {
-      HIPCHK(hipStreamSynchronize(d->stream));
-      memset((void *)d->hostbox_host, 0, sizeof(PeerBox));
-      __sync_synchronize();
-    }
-    else HIPCHK(hipMemsetAsync(d->xbox, 0, sizeof(PeerBox), d->stream));
+      if (d->hostbox_host)
+      {
+        if (!d->hostbox_mirror) HIPCHK(hipMalloc((void **)&d->hostbox_mirror, sizeof(PeerBox)));
+        HIPCHK(hipMemsetAsync(d->hostbox_mirror, 0, sizeof(PeerBox), d->stream));
+        pa.mirror = d->hostbox_mirror;
+      }
+      // my box is cleared BEFORE the collective below, which no remote launch can get past without my taking part:
+      // nobody writes a word of this run into it too early, and nothing of the last run survives
+      if (d->hostbox_host)
+      {
+        HIPCHK(hipStreamSynchronize(d->stream));
+        memset((void *)d->hostbox_host, 0, sizeof(PeerBox));
+        __sync_synchronize();
+      }
+      else HIPCHK(hipMemsetAsync(d->xbox, 0, sizeof(PeerBox), d->stream));
+      return RAMX_OK;
+    };
+    const int lrc = local_prep();
     if ((rc = host_allreduce_shards(d, d->d_sums)) != RAMX_OK) return rc;     // vote of row 0 (from K(-1)) over ranks
+    if (lrc != RAMX_OK) return lrc;
+    // test hook: RAMX_TEST_FAIL_PRK_RANK=<rank> makes that rank fail where a launch error would
+    const char *tf = getenv("RAMX_TEST_FAIL_PRK_RANK");
+    if (tf && atoi(tf) == d->rank) { ramx_set_error("test hook: forced failure of the persistent launch on rank %d", d->rank); return RAMX_ERR_HIP; }
   }
   memcpy(pa.tab, a.tab, sizeof(pa.tab));
   pa.pack_ok = getenv("RAMX_NO_FASTPACK") ? 0 : fast_pack_ok(pa.tab, a.go, a.ge, L, W);
   if (pa.pack_ok && getenv("RAMX_NO_MASKHI") == NULL) pa.pack_ok = 2;      // 2: the far-end-masked fast band may be used too
   HIPCHK(hipMemsetAsync(d->d_vote, 0, 3 * NSHARD * sizeof(PShard), d->stream));
   HIPCHK(hipMemsetAsync(d->d_err, 0, 64, d->stream));
-  *used = true;
 #ifdef RAMX_PRK_TIMING
   const size_t nw = (size_t)blocks * (block / 64);
   HIPCHK(hipMalloc((void **)&pa.dbg, nw * 8 * sizeof(unsigned long long)));
@@ -914,7 +925,7 @@ extern "C" int ramx_dev_run_direction(ramx_dev *d, ramx_run_info *info)
   const bool multi = (d->comm != NULL && d->nranks > 1) || d->cb != NULL;
 
   auto slot = [&](int r) { return d->d_sums + (size_t)(((r % 3) + 3) % 3) * NSHARD * 4; };
-  int launches = 0, nsamp = 0, pending = -1, chk = 0, lanes = 1;
+  int launches = 0, nsamp = 0, pending = -1, chk = 0, lanes = 1, prk_local_rc = RAMX_OK;
   bool persistent = false;
   // ---- cell-parallel route (single GPU): K lanes per flank, the whole direction in one cooperative launch of at most one
   // workgroup per CU; boundary row and every column inside the kernel ---------------------------------------------------
@@ -966,16 +977,29 @@ extern "C" int ramx_dev_run_direction(ramx_dev *d, ramx_run_info *info)
     // the in-place row buffer holds S(-1) after K(-1); d_ctl[1] holds the initial control block, the persistent
     // kernel writes its final one to d_ctl[0]
     if (d->d_state[0] != d->d_state[1]) { ramx_set_error("persistent path needs the in-place row buffer"); }
-    else { int prc = prk_run(d, a, L, &persistent); if (prc != RAMX_OK) return prc; }
+    else
+    {
+      prk_local_rc = prk_run(d, a, L, &persistent);
+      // Single GPU: a failure is simply returned.  Multi-rank: once the ranks have agreed on the persistent path
+      // (prk_run sets `persistent` after that agreement) a rank-local failure -- an allocation, a memset, the launch
+      // itself -- must NOT leave before the agreement below, or the other ranks' kernels spin to their limit and then
+      // wait in a collective this rank never joins.
+      if (prk_local_rc != RAMX_OK && !(multi && persistent)) return prk_local_rc;
+    }
   }
   if (persistent && multi)
   {
-    // agree over all ranks whether the cross-device launch went through; if any rank gave up (bounded spin), every
-    // rank repeats the direction with the per-column launches and the host collective
-    HIPCHK(hipStreamSynchronize(d->stream));
+    // agree over all ranks whether the cross-device launch went through; if any rank gave up (bounded spin) or failed
+    // locally, every rank repeats the direction with the per-column launches and the host collective
+    int bad = prk_local_rc != RAMX_OK;
     RamxCtl c0;
-    HIPCHK(hipMemcpy(&c0, d->d_ctl, sizeof(c0), hipMemcpyDeviceToHost));
-    int bad = c0.pad != 0;
+    memset(&c0, 0, sizeof(c0));
+    if (!bad)
+    {
+      if (hipStreamSynchronize(d->stream) != hipSuccess || hipMemcpy(&c0, d->d_ctl, sizeof(c0), hipMemcpyDeviceToHost) != hipSuccess) bad = 1;
+    }
+    else (void)hipStreamSynchronize(d->stream);
+    bad = bad || c0.pad != 0;
     int frc = host_allreduce_flag(d, &bad);
     if (frc != RAMX_OK) return frc;
     if (bad)

@@ -28,12 +28,43 @@ int ramx_runtime_when_to_stop(void) { return g_when_to_stop; }
 int ramx_runtime_l(void) { return g_l; }
 
 static ramx_dev *g_dev = NULL;
+/* The device keeps the library between calls (the reference's main() runs both directions on one seqLib).  The
+ * cache key is (pointer, length, content fingerprint): a caller that rewrites the buffer in place, or whose new
+ * library lands at a recycled address with the same length, must never be served the stale device copy.  Libraries
+ * above RAMX_FP_MAX bytes are not fingerprinted (reading 1 GB costs more than uploading it): they are uploaded again
+ * on every call.  ramx_invalidate_library() drops the cache explicitly. */
+#define RAMX_FP_MAX (64ull << 20)
 static const int8_t *g_lib_ptr = NULL;
-static uint64_t g_lib_len = 0;
-/* batch mode: the (pointer, length) of every family whose concatenation the device currently holds */
+static uint64_t g_lib_len = 0, g_lib_fp = 0;
+/* batch mode: the (pointer, length, fingerprint) of every family whose concatenation the device currently holds */
 static const int8_t **g_bl_ptr = NULL;
-static uint64_t *g_bl_len = NULL;
+static uint64_t *g_bl_len = NULL, *g_bl_fp = NULL;
 static int g_bl_n = 0;
+
+static uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+
+/* 64-bit content fingerprint, four independent multiply-rotate lanes over 32-byte stripes (memory-bound, ~10 GB/s) */
+static uint64_t fingerprint(const int8_t *p, uint64_t n)
+{
+  const uint64_t P1 = 0x9E3779B185EBCA87ull, P2 = 0xC2B2AE3D27D4EB4Full;
+  uint64_t a = P1 ^ n, b = P2, c = ~P1, d = ~P2, w[4];
+  uint64_t i = 0;
+  for (; i + 32 <= n; i += 32)
+  {
+    memcpy(w, p + i, 32);
+    a = rotl64(a + w[0] * P2, 31) * P1; b = rotl64(b + w[1] * P2, 31) * P1;
+    c = rotl64(c + w[2] * P2, 31) * P1; d = rotl64(d + w[3] * P2, 31) * P1;
+  }
+  uint64_t h = rotl64(a, 1) + rotl64(b, 7) + rotl64(c, 12) + rotl64(d, 18);
+  for (; i < n; i++) h = rotl64(h ^ ((uint64_t)(uint8_t)p[i] * P1), 11) * P2;
+  h ^= h >> 33; h *= P2; h ^= h >> 29; h *= P1; h ^= h >> 32;
+  return h ? h : 1;
+}
+
+void ramx_invalidate_library(void)
+{
+  g_lib_ptr = NULL; g_lib_len = 0; g_lib_fp = 0; g_bl_n = 0;
+}
 
 ramx_dev *ramx_default_device(void)
 {
@@ -110,12 +141,17 @@ int ramx_extend_flat(int direction, ramx_flat_cores *c, const int8_t *sequence, 
   const double t0 = wall_ms();
   const int N = c->n, W = p->bandwidth, L = p->L;
   int rc;
-  /* the library is shared by both directions: upload once per (pointer,length) */
-  if (sequence != g_lib_ptr || seq_len != g_lib_len)
+  /* the library is shared by both directions: upload once per (pointer, length, content) */
   {
-    if ((rc = ramx_dev_load_library(d, sequence, seq_len)) != RAMX_OK) return rc;
-    g_lib_ptr = sequence;
-    g_lib_len = seq_len;
+    const uint64_t fp = seq_len <= RAMX_FP_MAX ? fingerprint(sequence, seq_len) : 0;
+    if (sequence != g_lib_ptr || seq_len != g_lib_len || fp == 0 || fp != g_lib_fp)
+    {
+      g_lib_ptr = NULL; g_lib_len = 0; g_lib_fp = 0;
+      if ((rc = ramx_dev_load_library(d, sequence, seq_len)) != RAMX_OK) return rc;
+      g_lib_ptr = sequence;
+      g_lib_len = seq_len;
+      g_lib_fp = fp;
+    }
   }
   int *map = (int *)malloc(sizeof(int) * (N > 0 ? N : 1));
   ramx_flank *fl = (ramx_flank *)malloc(sizeof(ramx_flank) * (N > 0 ? N : 1));
@@ -299,9 +335,11 @@ int ramx_extend_batch(int direction, ramx_family *fam, int32_t F, const ramx_par
   uint64_t *at_of = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)(F ? F : 1));
   total_len = 0;
   for (int f = 0; f < F; f++) { at_of[f] = total_len; total_len += fam[f].seq_len; }
-  int lib_cached = (g_lib_ptr == (const int8_t *)&g_bl_n) && g_bl_n == F && g_lib_len == total_len;
+  int lib_cached = (g_lib_ptr == (const int8_t *)&g_bl_n) && g_bl_n == F && g_lib_len == total_len && total_len <= RAMX_FP_MAX;
+  uint64_t *fps = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)(F ? F : 1));
+  for (int f = 0; f < F; f++) fps[f] = total_len <= RAMX_FP_MAX ? fingerprint(fam[f].sequence, fam[f].seq_len) : 0;
   for (int f = 0; f < F && lib_cached; f++)
-    if (g_bl_ptr[f] != fam[f].sequence || g_bl_len[f] != fam[f].seq_len) lib_cached = 0;
+    if (g_bl_ptr[f] != fam[f].sequence || g_bl_len[f] != fam[f].seq_len || g_bl_fp[f] != fps[f]) lib_cached = 0;
   int8_t *lib = lib_cached ? NULL : (int8_t *)malloc(total_len ? total_len : 1);
   ramx_flank *fl = (ramx_flank *)malloc(sizeof(ramx_flank) * (total_pad ? total_pad : 1));
   int32_t *map = (int32_t *)malloc(sizeof(int32_t) * (total_pad ? total_pad : 1));
@@ -334,13 +372,14 @@ int ramx_extend_batch(int direction, ramx_family *fam, int32_t F, const ramx_par
     int32_t *tp = (int32_t *)malloc(sizeof(int32_t) * (fpos ? fpos : 1));
     if (!lib_cached)
     {
-      g_lib_ptr = NULL; g_lib_len = 0;               /* whatever library the device held is replaced */
+      g_lib_ptr = NULL; g_lib_len = 0; g_lib_fp = 0; /* whatever library the device held is replaced */
       rc = ramx_dev_load_library(d, lib, total_len);
       if (rc == RAMX_OK)
       {
         g_bl_ptr = (const int8_t **)realloc((void *)g_bl_ptr, sizeof(*g_bl_ptr) * (size_t)(F ? F : 1));
         g_bl_len = (uint64_t *)realloc(g_bl_len, sizeof(*g_bl_len) * (size_t)(F ? F : 1));
-        for (int f = 0; f < F; f++) { g_bl_ptr[f] = fam[f].sequence; g_bl_len[f] = fam[f].seq_len; }
+        g_bl_fp = (uint64_t *)realloc(g_bl_fp, sizeof(*g_bl_fp) * (size_t)(F ? F : 1));
+        for (int f = 0; f < F; f++) { g_bl_ptr[f] = fam[f].sequence; g_bl_len[f] = fam[f].seq_len; g_bl_fp[f] = fps[f]; }
         g_bl_n = F;
         g_lib_ptr = (const int8_t *)&g_bl_n;         /* sentinel: the device holds the batch library described by g_bl_* */
         g_lib_len = total_len;
@@ -381,7 +420,7 @@ int ramx_extend_batch(int direction, ramx_family *fam, int32_t F, const ramx_par
     int r1 = ramx_extend_flat(direction, &fam[f].cores, fam[f].sequence, fam[f].seq_len, fam[f].master, p, &infos[f]);
     if (r1 < 0) rc = r1;
   }
-  free(lib); free(at_of); free(fl); free(map); free(first); free(count); free(fidx); free(take); free(own);
+  free(lib); free(at_of); free(fl); free(map); free(first); free(count); free(fidx); free(take); free(own); free(fps);
   return rc;
 }
 

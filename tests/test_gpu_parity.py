@@ -170,3 +170,41 @@ def test_gpu_full_recurrence_path_and_positive_penalties(monkeypatch):
         assert np.array_equal(cons, m[p.L + 1: p.L + 1 + info.rows_executed])
         ok = (th > 0) & (tp >= 0)
         assert np.array_equal((tp[ok] + 1), c.right_len[idx[ok]]) and np.array_equal(th[ok], c.score[idx[ok]])
+
+
+def test_seam1_library_cache_sees_in_place_rewrite_and_recycled_buffers():
+    """Seam 1 keeps the library on the device between calls.  A buffer rewritten in place, or a new library that lands at
+    the same address with the same length, must be uploaded again (the reference reads the caller's buffer on every
+    call): results after the rewrite must equal the oracle's on the NEW content."""
+    from repeatafterme_amd.synth import synth_family
+    p = po.Params.named("14p43g", bandwidth=14, L=120, when_to_stop=30)
+    a = synth_family(150, 120, 14, K=80, seed=91, both_sides=True, minus_frac=0.3)
+    b = synth_family(150, 120, 14, K=80, seed=92, both_sides=True, minus_frac=0.3)
+    assert len(a.sequence) == len(b.sequence)
+    buf = a.sequence.copy()
+    x = run_both_directions(oracle_extend, a.cores, a.sequence, p)
+    y = run_both_directions(gpu_extend, a.cores, buf, p)
+    assert_same_result(x[0], x[1], x[2:], y[0], y[1], y[2:], "first library")
+    buf[:] = b.sequence                                   # same pointer, same length, new content
+    x = run_both_directions(oracle_extend, b.cores, b.sequence, p)
+    y = run_both_directions(gpu_extend, b.cores, buf, p)
+    assert_same_result(x[0], x[1], x[2:], y[0], y[1], y[2:], "rewritten in place")
+    assert not np.array_equal(x[1], run_both_directions(oracle_extend, a.cores, a.sequence, p)[1])
+    # batch mode: one family of the batch rewritten in place between two calls
+    from repeatafterme_amd.datamodel import new_master
+    from repeatafterme_amd.extend import extend_batch
+    fams = [synth_family(40 + 10 * i, 120, 14, K=70, seed=200 + i) for i in range(4)]
+    bufs = [f.sequence.copy() for f in fams]
+    ep = to_extend_params(p)
+    for rnd in range(2):
+        if rnd == 1:
+            alt = synth_family(40, 120, 14, K=70, seed=999)
+            assert len(alt.sequence) == len(bufs[0])
+            bufs[0][:] = alt.sequence
+            fams[0] = alt
+        cs = [f.cores.copy() for f in fams]; ms = [new_master(p.L) for _ in fams]
+        extend_batch(1, [(c, s_, m) for c, s_, m in zip(cs, bufs, ms)], ep)
+        for f, c, m in zip(fams, cs, ms):
+            c0 = f.cores.copy(); m0 = new_master(p.L)
+            po.oracle_extend(1, c0, f.sequence, m0, p)
+            assert np.array_equal(m, m0) and np.array_equal(c.right_len, c0.right_len) and np.array_equal(c.score, c0.score), rnd

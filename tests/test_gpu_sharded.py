@@ -21,7 +21,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out, peer=False, W=20, kind=""):
+def _worker(rank, world, port, out, peer=False, W=20, kind="", fail_rank=None):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -48,6 +48,8 @@ def _worker(rank, world, port, out, peer=False, W=20, kind=""):
 
     fs = synth_family(333, 150, W, K=100, seed=12, both_sides=True, minus_frac=0.3, n_run_frac=0.1)
     p = po.Params.named("14p43g", bandwidth=W, L=150, when_to_stop=25)
+    if fail_rank is not None:
+        os.environ["RAMX_TEST_FAIL_PRK_RANK"] = str(fail_rank)
     dev = Device(0)
     dev.set_allreduce_callback(allreduce4)
     enabled = False
@@ -115,6 +117,29 @@ def test_two_ranks_cross_device_persistent_path(W, kind):
         rets, mm, ll, rl, sc, enabled, used = out[rank]
         assert enabled, "peer self-test failed"
         assert used == 1, "cross-device persistent launch was not taken (or fell back)"
+        assert rets == [(r1.ret, r1.rows_executed), (r0.ret, r0.rows_executed)], rank
+        assert np.array_equal(mm, m) and np.array_equal(ll, c.left_len) and np.array_equal(rl, c.right_len)
+        assert np.array_equal(sc, c.score)
+
+
+def test_rank_local_failure_after_agreement_falls_back_on_all_ranks():
+    """A rank whose persistent launch fails AFTER the ranks have agreed on the mailbox path (forced by a test hook) must
+    still take part in the second agreement: every rank then repeats the direction with per-column launches -- nobody
+    hangs in a collective the failed rank never joins, and the results are still the oracle's."""
+    from oracle import pyoracle as po
+    from repeatafterme_amd.datamodel import new_master
+    from repeatafterme_amd.synth import synth_family
+    world = 2
+    out = mp.Manager().dict()
+    mp.spawn(_worker, args=(world, _free_port(), out, True, 20, "host", 1), nprocs=world, join=True)
+    fs = synth_family(333, 150, 20, K=100, seed=12, both_sides=True, minus_frac=0.3, n_run_frac=0.1)
+    p = po.Params.named("14p43g", bandwidth=20, L=150, when_to_stop=25)
+    c = fs.cores.copy(); m = new_master(p.L)
+    r1 = po.oracle_extend(1, c, fs.sequence, m, p); r0 = po.oracle_extend(0, c, fs.sequence, m, p)
+    for rank in range(world):
+        rets, mm, ll, rl, sc, enabled, used = out[rank]
+        assert enabled
+        assert used == 0, "the direction must have been repeated with per-column launches on every rank"
         assert rets == [(r1.ret, r1.rows_executed), (r0.ret, r0.rows_executed)], rank
         assert np.array_equal(mm, m) and np.array_equal(ll, c.left_len) and np.array_equal(rl, c.right_len)
         assert np.array_equal(sc, c.score)
