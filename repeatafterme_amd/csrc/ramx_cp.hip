@@ -131,10 +131,17 @@ static int cp_launch_dev(hipStream_t st, int threads, int blocks, const CPArgs &
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return RAMX_ERR_HIP;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ramx_cp_kernel<W, K, true>, threads, 0) != hipSuccess) return RAMX_ERR_HIP;
     if (per_cu < 1 || blocks > cus) return RAMX_ERR_UNSUPPORTED;      // one workgroup per CU by design
-    CPArgs copy = a;
-    void *args[] = { (void *)&copy };
-    hipError_t e = hipLaunchCooperativeKernel((const void *)ramx_cp_kernel<W, K, true>, dim3(blocks), dim3(threads), args, 0, st);
-    return e == hipSuccess ? RAMX_OK : RAMX_ERR_HIP;
+    // plain launch (see prk_launch in ramx_device.hip: the co-residency check is done here, the kernel's barrier is
+    // bounded, and a cooperative launch makes rocprofv3-profiled processes crash at exit); RAMX_COOP_LAUNCH=1 restores it
+    if (getenv("RAMX_COOP_LAUNCH") != NULL)
+    {
+      CPArgs copy = a;
+      void *args[] = { (void *)&copy };
+      hipError_t e = hipLaunchCooperativeKernel((const void *)ramx_cp_kernel<W, K, true>, dim3(blocks), dim3(threads), args, 0, st);
+      return e == hipSuccess ? RAMX_OK : RAMX_ERR_HIP;
+    }
+    hipLaunchKernelGGL((ramx_cp_kernel<W, K, true>), dim3(blocks), dim3(threads), 0, st, a);
+    return hipGetLastError() == hipSuccess ? RAMX_OK : RAMX_ERR_HIP;
   }
 }
 

@@ -107,6 +107,7 @@ struct ramx_dev
   ramx_allreduce_cb cb; void *cb_user;
   // cross-device persistent path: this rank's box (fine-grained), every rank's box as mapped here, device copy of that table
   PeerBox *xbox; PeerBox *peer[RAMX_MAX_RANKS]; PeerBox **d_peer; int peer_ready;
+  void *peer_ipc[RAMX_MAX_RANKS];   // what hipIpcOpenMemHandle returned for the other ranks' boxes (closed on re-import / destroy)
   // host-memory variant of the boxes (POSIX shared memory registered with HIP): xbox/peer point into it
   void *hostbox_map; size_t hostbox_bytes; PeerBox *hostbox_host; int hostbox_registered;
   PeerBox *hostbox_mirror;   // device-memory copy of my host box, kept current by block 0 (the other blocks poll it)
@@ -140,17 +141,21 @@ extern "C" int ramx_dev_create(int ordinal, ramx_dev **out)
   }
   ramx_dev *d = (ramx_dev *)calloc(1, sizeof(ramx_dev));
   d->ordinal = ordinal;
-  HIPCHK(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
-  HIPCHK(hipHostMalloc((void **)&d->h_ctl, 4 * sizeof(RamxCtl), hipHostMallocDefault));
-  HIPCHK(hipMalloc((void **)&d->d_sums, (3 * NSHARD * 4 + 8) * sizeof(long long)));
-  HIPCHK(hipMalloc((void **)&d->d_ctl, 2 * sizeof(RamxCtl)));
-  HIPCHK(hipMalloc((void **)&d->d_vote, 3 * NSHARD * sizeof(PShard)));
-  HIPCHK(hipMalloc((void **)&d->d_err, 64));
+  // any failure below releases what has been created so far (ramx_dev_destroy copes with a partly built session)
+#define CRCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
+    ramx_set_error("HIP error %s at %s:%d (%s)", hipGetErrorString(e_), __FILE__, __LINE__, #call); ramx_dev_destroy(d); return RAMX_ERR_HIP; } } while (0)
+  CRCHK(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
+  CRCHK(hipHostMalloc((void **)&d->h_ctl, 4 * sizeof(RamxCtl), hipHostMallocDefault));
+  CRCHK(hipMalloc((void **)&d->d_sums, (3 * NSHARD * 4 + 8) * sizeof(long long)));
+  CRCHK(hipMalloc((void **)&d->d_ctl, 2 * sizeof(RamxCtl)));
+  CRCHK(hipMalloc((void **)&d->d_vote, 3 * NSHARD * sizeof(PShard)));
+  CRCHK(hipMalloc((void **)&d->d_err, 64));
 
-  for (int i = 0; i < 2; i++) HIPCHK(hipEventCreate(&d->ev_chk[i]));
-  HIPCHK(hipEventCreate(&d->ev_begin));
-  HIPCHK(hipEventCreate(&d->ev_end));
-  for (int i = 0; i < MAX_SAMPLES; i++) { HIPCHK(hipEventCreate(&d->ev_s0[i])); HIPCHK(hipEventCreate(&d->ev_s1[i])); }
+  for (int i = 0; i < 2; i++) CRCHK(hipEventCreate(&d->ev_chk[i]));
+  CRCHK(hipEventCreate(&d->ev_begin));
+  CRCHK(hipEventCreate(&d->ev_end));
+  for (int i = 0; i < MAX_SAMPLES; i++) { CRCHK(hipEventCreate(&d->ev_s0[i])); CRCHK(hipEventCreate(&d->ev_s1[i])); }
+#undef CRCHK
   const char *eb = getenv("RAMX_FORCE_CHAIN");
   d->force_chain = (eb && atoi(eb) != 0) ? 1 : 0;
   *out = d;
@@ -161,12 +166,15 @@ extern "C" void ramx_dev_destroy(ramx_dev *d)
 {
   if (!d) return;
   (void)hipSetDevice(d->ordinal);
-  (void)hipStreamSynchronize(d->stream);
+  if (d->stream) (void)hipStreamSynchronize(d->stream);
   if (d->comm) (void)ncclCommDestroy(d->comm);
+  // mappings of the other ranks' mailboxes (hipIpcOpenMemHandle): closed before anything of this device is released
+  for (int q = 0; q < RAMX_MAX_RANKS; q++)
+    if (d->peer_ipc[q]) { (void)hipIpcCloseMemHandle(d->peer_ipc[q]); d->peer_ipc[q] = NULL; }
   (void)hipFree(d->d_lib); (void)hipFree(d->d_flanks); (void)hipFree(d->d_bases); (void)hipFree(d->d_bounds);
   (void)hipFree(d->d_state[0]); if (d->d_state[1] != d->d_state[0]) (void)hipFree(d->d_state[1]); (void)hipFree(d->d_trim); (void)hipFree(d->d_sums);
   (void)hipFree(d->d_ctl); (void)hipFree(d->d_cons); (void)hipFree(d->d_vote); (void)hipFree(d->d_err);
-  (void)hipHostFree(d->h_ctl);
+  if (d->h_ctl) (void)hipHostFree(d->h_ctl);
   if (d->hostbox_map)
   {
     if (d->hostbox_registered) (void)hipHostUnregister(d->hostbox_map);
@@ -181,10 +189,11 @@ extern "C" void ramx_dev_destroy(ramx_dev *d)
   (void)hipFree(d->d_fam); (void)hipFree(d->d_famctl); (void)hipFree(d->d_cpstate);
   if (d->hostbox_mirror) (void)hipFree(d->hostbox_mirror);
   if (d->d_peer) (void)hipFree(d->d_peer);
-  for (int i = 0; i < 2; i++) (void)hipEventDestroy(d->ev_chk[i]);
-  (void)hipEventDestroy(d->ev_begin); (void)hipEventDestroy(d->ev_end);
-  for (int i = 0; i < MAX_SAMPLES; i++) { (void)hipEventDestroy(d->ev_s0[i]); (void)hipEventDestroy(d->ev_s1[i]); }
-  (void)hipStreamDestroy(d->stream);
+  for (int i = 0; i < 2; i++) if (d->ev_chk[i]) (void)hipEventDestroy(d->ev_chk[i]);
+  if (d->ev_begin) (void)hipEventDestroy(d->ev_begin);
+  if (d->ev_end) (void)hipEventDestroy(d->ev_end);
+  for (int i = 0; i < MAX_SAMPLES; i++) { if (d->ev_s0[i]) (void)hipEventDestroy(d->ev_s0[i]); if (d->ev_s1[i]) (void)hipEventDestroy(d->ev_s1[i]); }
+  if (d->stream) (void)hipStreamDestroy(d->stream);
   free(d);
 }
 
@@ -358,6 +367,8 @@ extern "C" int ramx_dev_peer_import(ramx_dev *d, const uint8_t *handles, int ran
   d->peer_ready = 0;
   d->rank = rank; d->nranks = nranks;
   d->xbox = d->devbox; d->hostbox_host = NULL;
+  for (int q = 0; q < RAMX_MAX_RANKS; q++)
+    if (d->peer_ipc[q]) { (void)hipIpcCloseMemHandle(d->peer_ipc[q]); d->peer_ipc[q] = NULL; }
   for (int q = 0; q < nranks; q++)
   {
     if (q == rank) { d->peer[q] = d->xbox; continue; }
@@ -367,6 +378,7 @@ extern "C" int ramx_dev_peer_import(ramx_dev *d, const uint8_t *handles, int ran
     hipError_t e = hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess);
     if (e != hipSuccess) { ramx_set_error("hipIpcOpenMemHandle(rank %d): %s", q, hipGetErrorString(e)); return RAMX_ERR_HIP; }
     d->peer[q] = (PeerBox *)ptr;
+    d->peer_ipc[q] = ptr;
   }
   if (!d->d_peer) HIPCHK(hipMalloc((void **)&d->d_peer, RAMX_MAX_RANKS * sizeof(PeerBox *)));
   HIPCHK(hipMemcpy(d->d_peer, d->peer, nranks * sizeof(PeerBox *), hipMemcpyHostToDevice));
@@ -384,9 +396,11 @@ extern "C" int ramx_dev_hostbox_attach(ramx_dev *d, const char *shm_name, int ra
   HIPCHK(hipSetDevice(d->ordinal));
   d->peer_ready = 0;
   const size_t bytes = (((size_t)nranks * sizeof(PeerBox)) + 4095) & ~(size_t)4095;
-  int fd = shm_open(shm_name, O_CREAT | O_RDWR, 0600);
+  // rank 0 creates the segment exclusively (a leftover or pre-created segment of that name is an error, never silently
+  // adopted) and sizes it; the other ranks open it -- the caller synchronises the ranks between rank 0's call and theirs
+  int fd = rank == 0 ? shm_open(shm_name, O_CREAT | O_EXCL | O_RDWR, 0600) : shm_open(shm_name, O_RDWR, 0600);
   if (fd < 0) { ramx_set_error("shm_open(%s): %s", shm_name, strerror(errno)); return RAMX_ERR_COMM; }
-  if (ftruncate(fd, (off_t)bytes) != 0) { ramx_set_error("ftruncate(%s): %s", shm_name, strerror(errno)); close(fd); return RAMX_ERR_COMM; }
+  if (rank == 0 && ftruncate(fd, (off_t)bytes) != 0) { ramx_set_error("ftruncate(%s): %s", shm_name, strerror(errno)); close(fd); shm_unlink(shm_name); return RAMX_ERR_COMM; }
   void *map = mmap(NULL, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
   close(fd);
   if (map == MAP_FAILED) { ramx_set_error("mmap(%s): %s", shm_name, strerror(errno)); return RAMX_ERR_COMM; }
@@ -485,8 +499,21 @@ static int prk_capacity_blocks(int *out)
 template <int W, int BLOCK>
 static int prk_launch(ramx_dev *d, PArgs &pa, int blocks)
 {
-  void *args[] = { (void *)&pa };
-  HIPCHK(hipLaunchCooperativeKernel((const void *)ramx_persistent_kernel<W, BLOCK>, dim3(blocks), dim3(BLOCK), args, 0, d->stream));
+  // A PLAIN launch.  hipLaunchCooperativeKernel buys only the launch-time comparison of the grid with the occupancy query
+  // (MI355X_MICROARCH.md, "coop-launch") -- prk_plan has made that comparison already (at most one workgroup per CU, never
+  // more workgroups than CUs) -- and costs 15-19 us of host time per launch; the kernel has its own bounded barrier and
+  // never calls grid.sync().  It also made every process that was profiled with rocprofv3 die with SIGSEGV inside exit():
+  // the runtime's cooperative queue is torn down after the tool has finalised (tools/rocprof_exit_probe.sh isolates it:
+  // streaming launches exit cleanly, one cooperative launch does not, with or without ramx_dev_destroy).
+  // RAMX_COOP_LAUNCH=1 restores the cooperative launch.
+  if (getenv("RAMX_COOP_LAUNCH") != NULL)
+  {
+    void *args[] = { (void *)&pa };
+    HIPCHK(hipLaunchCooperativeKernel((const void *)ramx_persistent_kernel<W, BLOCK>, dim3(blocks), dim3(BLOCK), args, 0, d->stream));
+    return RAMX_OK;
+  }
+  hipLaunchKernelGGL((ramx_persistent_kernel<W, BLOCK>), dim3(blocks), dim3(BLOCK), 0, d->stream, pa);
+  HIPCHK(hipGetLastError());
   return RAMX_OK;
 }
 
@@ -651,7 +678,7 @@ extern "C" int ramx_dev_run_families(ramx_dev *d, const ramx_flank *flanks, int3
   int maxn = 0;
   for (int f = 0; f < n_families; f++)
   {
-    if (fam_count[f] < 0 || (fam_first[f] & 63) || fam_first[f] + fam_count[f] > n_padded) { ramx_set_error("ramx_dev_run_families: bad family layout"); return RAMX_ERR_ARG; }
+    if (fam_count[f] < 0 || fam_first[f] < 0 || (fam_first[f] & 63) || (long long)fam_first[f] + fam_count[f] > n_padded) { ramx_set_error("ramx_dev_run_families: bad family layout"); return RAMX_ERR_ARG; }
     if (fam_count[f] > maxn) maxn = fam_count[f];
   }
   if (maxn > 512) { ramx_set_error("batch mode: a family has more than 512 flanks"); return RAMX_ERR_UNSUPPORTED; }
@@ -730,6 +757,7 @@ extern "C" int ramx_dev_run_families(ramx_dev *d, const ramx_flank *flanks, int3
   hipLaunchKernelGGL(ramx_pack_kernel, dim3((Np + 255) / 256, KW), dim3(256), 0, d->stream, d->d_lib, (unsigned long long)d->lib_len,
                      d->d_flanks, n_padded, Np, W, d->d_bases, d->d_bounds);
   FAMCHK(hipGetLastError());
+  FAMCHK(hipMemsetAsync(d->d_cons, 0, (size_t)n_families * (L > 0 ? L : 1) + 16, d->stream));   // columns a family never ran read as 0
   memset(&fa, 0, sizeof(fa));
   fa.bases = d->d_bases; fa.bounds = d->d_bounds; fa.fam = dfd; fa.trim = d->d_trim; fa.ctl_out = dctl; fa.cons_out = d->d_cons;
   fa.Np = Np; fa.L = L; fa.go = p->gapopen; fa.ge = p->gapextn; fa.cap = p->cappenalty; fa.minimp = p->minimprovement;

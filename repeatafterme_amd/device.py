@@ -134,16 +134,24 @@ class Device:
                 self.peer_kind = "device"
                 return True
         if only in ("", "host"):
-            # one name for the job: rank 0's pid, spread through the same all-gather
+            # one name for the job: rank 0's pid + a random nonce, spread through the same all-gather; rank 0 creates the
+            # segment exclusively, the others open it after a barrier; the name is unlinked in any case
             mine = np.zeros(64, np.uint8)
-            tag = (b"/ramx_box_%d" % os.getpid())[:63]
+            tag = (b"/ramx_box_%d_%s" % (os.getpid(), os.urandom(8).hex().encode()))[:63]
             mine[:len(tag)] = np.frombuffer(tag, np.uint8)
             name = bytes(all_gather_bytes(mine.tobytes())[0]).split(b"\0", 1)[0]
-            ok = 1 if self._L.ramx_dev_hostbox_attach(self._h, name, rank, world) >= 0 else 0
-            barrier()                       # every box exists and has been cleared by its owner
-            ok = selftest(ok)
-            if rank == 0:
-                self._L.ramx_hostbox_unlink(name)
+            ok = 1
+            try:
+                if rank == 0:
+                    ok = 1 if self._L.ramx_dev_hostbox_attach(self._h, name, rank, world) >= 0 else 0
+                barrier()                   # the segment exists (or rank 0 failed: the others then fail to open it)
+                if rank != 0:
+                    ok = 1 if self._L.ramx_dev_hostbox_attach(self._h, name, rank, world) >= 0 else 0
+                barrier()                   # every box has been cleared by its owner
+                ok = selftest(ok)
+            finally:
+                if rank == 0:
+                    self._L.ramx_hostbox_unlink(name)
             if ok == 1:
                 self._L.ramx_dev_peer_enable(self._h, 1)
                 self.peer_kind = "host"
