@@ -99,6 +99,39 @@ __device__ __forceinline__ void cp_flank_sum4(unsigned (&v)[4])
   for (int k = 0; k < 4; k++) v[k] = (unsigned)__builtin_amdgcn_readlane((int)v[k], 63);
 }
 
+// byte BYTE of `word` (a class index times 4), as it is / times 4: LDS offsets of the 4-byte and the 16-byte table rows
+template <int BYTE>
+__device__ __forceinline__ unsigned cp_byte(unsigned word)
+{
+  unsigned d;
+  if (BYTE == 0) asm("v_mov_b32_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0" : "=v"(d) : "v"(word));
+  else if (BYTE == 1) asm("v_mov_b32_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1" : "=v"(d) : "v"(word));
+  else if (BYTE == 2) asm("v_mov_b32_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2" : "=v"(d) : "v"(word));
+  else asm("v_mov_b32_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3" : "=v"(d) : "v"(word));
+  return d;
+}
+template <int BYTE>
+__device__ __forceinline__ unsigned cp_byte_x4(unsigned word)
+{
+  unsigned d;
+  if (BYTE == 0) asm("v_lshlrev_b32_sdwa %0, 2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(d) : "v"(word));
+  else if (BYTE == 1) asm("v_lshlrev_b32_sdwa %0, 2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(d) : "v"(word));
+  else if (BYTE == 2) asm("v_lshlrev_b32_sdwa %0, 2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(d) : "v"(word));
+  else asm("v_lshlrev_b32_sdwa %0, 2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(d) : "v"(word));
+  return d;
+}
+
+// Score tables in LDS.  win[b][class] = M[b][class]: the substitution score of the row being computed (winner b of the
+// vote), one ds_read_b32 per cell at (4 * class + 64 * b).  cand[class] = {M[A][class], M[C][class], M[G][class],
+// M[T][class]} as four int32, one ds_read_b128 per cell: the candidates' adds are then plain v_add_u32 on two vector
+// registers, which issue at twice the rate of the SDWA byte adds a packed row needs (tools/microbench/valu_rate.hip).
+// Rows of one table sit in different LDS banks, lanes reading the same class broadcast.
+struct CpTabs
+{
+  int4 cand[16];
+  int win[4][16];
+};
+
 template <int W, int K>
 struct CpCfg
 {
@@ -152,8 +185,8 @@ __device__ __forceinline__ int cp_fill(int iWr, int edge)      // (I < iWr) ? ed
 
 // Row r from row r-1 (bnw_extend.c:750-1048), cells split over the group.  G: masked (general) path.
 template <int W, int K, bool G>
-__device__ __forceinline__ void cp_update(const CpLane &ln, const int go, const int ge, const int sh8, const int edgeFx,
-                                          const int (&T)[CpCfg<W, K>::C + 1], int (&m)[CpCfg<W, K>::C], int (&e)[CpCfg<W, K>::C])
+__device__ __forceinline__ void cp_update(const CpLane &ln, const int go, const int ge, const int edgeFx,
+                                          const int (&sFv)[CpCfg<W, K>::C], int (&m)[CpCfg<W, K>::C], int (&e)[CpCfg<W, K>::C])
 {
   typedef CpCfg<W, K> Cfg;
   constexpr int C = Cfg::C, IB = Cfg::IB;
@@ -182,8 +215,7 @@ __device__ __forceinline__ void cp_update(const CpLane &ln, const int go, const 
     constexpr int i = decltype(ic)::value;
     // masked path: keep the scheduler from hoisting every cell's fills and range tests to the top of the block
     if constexpr ((i % (G ? CP_G_GROUP : CP_F_GROUP)) == 0) __builtin_amdgcn_sched_barrier(0);
-    const int sF = __builtin_amdgcn_sbfe(T[i], sh8, 8);          // M[besta][base]: byte `besta` of the packed scores
-    const int sub = m[i] + sF;                                   // :950-956
+    const int sub = m[i] + sFv[i];                               // :950-956, sFv[i] = M[besta][base of cell i]
     int del = peNext;                                            // :892-905
     if constexpr (i + 1 < C) del = e[i + 1];
     if constexpr (i == IB) del = ln.pPart ? NEG : del;           // cell 2W has no deletion predecessor
@@ -223,7 +255,8 @@ __device__ __forceinline__ void cp_update(const CpLane &ln, const int go, const 
 // Best cell of row r (value, lowest cell on ties: bnw_extend.c:1020-1024) and the best cells of the four candidate rows
 // r+1 (chain-free rule of ramx_kernels_common.h), reduced over the group: every lane returns the same values.
 template <int W, int K, bool G>
-__device__ __forceinline__ void cp_reduce(const CpLane &ln, const int (&T)[CpCfg<W, K>::C + 1], const int (&m)[CpCfg<W, K>::C],
+__device__ __forceinline__ void cp_reduce(const CpLane &ln, const CpTabs &tabs, const unsigned (&AE)[CpCfg<W, K>::NA],
+                                          const unsigned (&AO)[CpCfg<W, K>::NA], const int (&m)[CpCfg<W, K>::C],
                                           const int (&e)[CpCfg<W, K>::C], int &bestF, int &jbest, int (&bestA)[4])
 {
   typedef CpCfg<W, K> Cfg;
@@ -239,8 +272,11 @@ __device__ __forceinline__ void cp_reduce(const CpLane &ln, const int (&T)[CpCfg
     else if constexpr (i > IB) key = ln.pFull ? key : CP_IMIN;
     int ms = m[i];
     if (G) ms = cp_sel_in(i + ln.nclo, ln.cspan, ms, SENT);
-    const int t4[4] = { add_sext_byte<0>(ms, T[i + 1]), add_sext_byte<1>(ms, T[i + 1]), add_sext_byte<2>(ms, T[i + 1]),
-                        add_sext_byte<3>(ms, T[i + 1]) };
+    // candidate cell i of row r+1 is aligned to the base of row r's cell i+1
+    constexpr int in = i + 1;
+    const unsigned off = cp_byte_x4<((in & 7) >> 1)>((in & 1) ? AO[in >> 3] : AE[in >> 3]);
+    const int4 sc = *reinterpret_cast<const int4 *>(reinterpret_cast<const char *>(&tabs.cand[0]) + off);
+    const int t4[4] = { ms + sc.x, ms + sc.y, ms + sc.z, ms + sc.w };
     int ev = e[i];
     if constexpr (i == 0) ev = ln.pL0 ? CP_IDN : ev;             // e of cell 0 is nobody's deletion term
     if constexpr ((i & 1) == 0 && i + 1 < C)
@@ -286,8 +322,11 @@ __device__ __forceinline__ void cp_reduce(const CpLane &ln, const int (&T)[CpCfg
 #define CP_TICK(k) do { } while (0)
 #endif
 
+#ifndef CP_MIN_WAVES_PER_SIMD
+#define CP_MIN_WAVES_PER_SIMD 2      // 512 threads, 2 waves per SIMD: 256 VGPRs
+#endif
 template <int W, int K, bool DEV>
-__global__ __launch_bounds__((CpCfg<W, K>::MAXT > 0 ? CpCfg<W, K>::MAXT : 64)) void ramx_cp_kernel(const CPArgs a)
+__global__ __launch_bounds__((CpCfg<W, K>::MAXT > 0 ? CpCfg<W, K>::MAXT : 64), CP_MIN_WAVES_PER_SIMD) void ramx_cp_kernel(const CPArgs a)
 {
   typedef CpCfg<W, K> Cfg;
   constexpr int B = Cfg::B, C = Cfg::C, NA = Cfg::NA, NWL = Cfg::NWL, FPW = 64 / K;
@@ -295,9 +334,9 @@ __global__ __launch_bounds__((CpCfg<W, K>::MAXT > 0 ? CpCfg<W, K>::MAXT : 64)) v
   static_assert(B <= 255, "cell index must fit the key's low byte");
   struct Smem
   {
-    int tab[16];                                     // class -> {M[A][b] | M[C][b] | M[G][b] | M[T][b]} as four int8
+    CpTabs tabs;                                     // first: the table rows are addressed with 16-bit immediate offsets
     unsigned long long vote[3][4];                   // DEV: [0..1] = this workgroup's partial sums (double buffered), [2] = the device-wide vote
-    int fail, pad[3];
+    int fail, pred, pad[2];                         // pred: this workgroup's own argmax for the next row (speculation)
   };
   __shared__ __attribute__((aligned(16))) Smem sm;
   // wave index through readfirstlane: `live` must be PROVABLY wave-uniform, or the band sits in a divergent region and
@@ -323,11 +362,10 @@ __global__ __launch_bounds__((CpCfg<W, K>::MAXT > 0 ? CpCfg<W, K>::MAXT : 64)) v
   if (threadIdx.x < 16)
   {
     const int cls = threadIdx.x;
-    unsigned pk = 0;
-    if (cls < RAMX_NCLASS)
-      pk = ((unsigned)a.tab[cls][0] & 0xffu) | (((unsigned)a.tab[cls][1] & 0xffu) << 8) | (((unsigned)a.tab[cls][2] & 0xffu) << 16) |
-           (((unsigned)a.tab[cls][3] & 0xffu) << 24);
-    sm.tab[cls] = (int)pk;
+    int4 v = make_int4(0, 0, 0, 0);
+    if (cls < RAMX_NCLASS) v = make_int4(a.tab[cls][0], a.tab[cls][1], a.tab[cls][2], a.tab[cls][3]);
+    sm.tabs.cand[cls] = v;
+    sm.tabs.win[0][cls] = v.x; sm.tabs.win[1][cls] = v.y; sm.tabs.win[2][cls] = v.z; sm.tabs.win[3][cls] = v.w;
   }
   if (threadIdx.x < 12) sm.vote[threadIdx.x >> 2][threadIdx.x & 3] = 0ULL;
   if (threadIdx.x == 0) sm.fail = 0;
@@ -367,28 +405,38 @@ __global__ __launch_bounds__((CpCfg<W, K>::MAXT > 0 ? CpCfg<W, K>::MAXT : 64)) v
       w[k] = a.bases[(size_t)wi * a.Np + n];
     }, std::make_integer_sequence<int, NWL + 1>{});
   }
-  const char *tb = reinterpret_cast<const char *>(&sm.tab[0]);
-
   // ---- pieces of a column --------------------------------------------------------------------
-  // table rows of cells 0 .. C of this block (cell C: the candidates' base of the block's last cell)
-  auto lookups = [&](int (&T)[C + 1]) __attribute__((always_inline))
+  // the lane's base window as LDS offsets: byte b of AE[k] / AO[k] = 4 * class of cell 8k + 2b / 8k + 2b + 1 (cells 0 .. C:
+  // cell C is the candidates' base of the block's last cell).  They depend only on the base stream and are computed at
+  // the end of the previous column, ahead of the vote exchange.
+  auto window_words = [&](unsigned (&AE)[NA], unsigned (&AO)[NA]) __attribute__((always_inline))
   {
     const int ph4 = 4 * (s & 7);
-    unsigned AE[NA], AO[NA];
     static_for([&](auto kc) __attribute__((always_inline))
     {
       constexpr int k = decltype(kc)::value;
       const unsigned A = __builtin_amdgcn_alignbit(w[k + 1], w[k], ph4);
-      AE[k] = (A << 2) & 0x3c3c3c3cu;                // byte b: 4 * (nibble 2b)
-      AO[k] = (A >> 2) & 0x3c3c3c3cu;                // byte b: 4 * (nibble 2b+1)
+      AE[k] = (A << 2) & 0x3c3c3c3cu;
+      AO[k] = (A >> 2) & 0x3c3c3c3cu;
     }, std::make_integer_sequence<int, NA>{});
+  };
+  // substitution scores of row r's cells against the winner `besta`: win[besta][class]
+  auto winner_scores = [&](const unsigned (&AE)[NA], const unsigned (&AO)[NA], const int besta, int (&sFv)[C]) __attribute__((always_inline))
+  {
+    const unsigned bb = 0x40404040u * (unsigned)besta;           // + 64 * besta in every byte (4 * class <= 60)
+    unsigned WE[NA], WO[NA];
+    static_for([&](auto kc) __attribute__((always_inline))
+    {
+      constexpr int k = decltype(kc)::value;
+      WE[k] = AE[k] | bb; WO[k] = AO[k] | bb;
+    }, std::make_integer_sequence<int, NA>{});
+    const char *tw = reinterpret_cast<const char *>(&sm.tabs.win[0][0]);
     static_for([&](auto ic) __attribute__((always_inline))
     {
       constexpr int i = decltype(ic)::value;
-      const unsigned src = (i & 1) ? AO[i >> 3] : AE[i >> 3];
-      const unsigned off = __builtin_amdgcn_ubfe(src, 8 * ((i & 7) >> 1), 8);
-      T[i] = *reinterpret_cast<const int *>(tb + off);
-    }, std::make_integer_sequence<int, C + 1>{});
+      const unsigned off = cp_byte<((i & 7) >> 1)>((i & 1) ? WO[i >> 3] : WE[i >> 3]);
+      sFv[i] = *reinterpret_cast<const int *>(tw + off);
+    }, std::make_integer_sequence<int, C>{});
   };
   auto set_masks = [&](int r) __attribute__((always_inline))
   {
@@ -426,7 +474,8 @@ __global__ __launch_bounds__((CpCfg<W, K>::MAXT > 0 ? CpCfg<W, K>::MAXT : 64)) v
   // (r+2) % 3 (last read at the top of column r-1, next added to during column r+1; the barrier at the end of every
   // column separates the three uses).
   // Device-wide vote (DEV = true): the waves add into the workgroup's partial sums [(r+1) & 1]; after the barrier four
-  // threads forward them, with the arrival ticket, to this workgroup's shard of device set (r+1) % 3 and clear them.
+  // threads forward them, with the arrival ticket, to this workgroup's shard of device set (r+1) % 3 and clear the other
+  // buffer; every wave reads the sums it has just helped to build as the workgroup's PREDICTION of the next vote.
   auto publish = [&](int r, unsigned (&contrib)[4]) __attribute__((always_inline))
   {
     if (live)
@@ -447,7 +496,7 @@ __global__ __launch_bounds__((CpCfg<W, K>::MAXT > 0 ? CpCfg<W, K>::MAXT : 64)) v
       if (threadIdx.x < 4)
       {
         const unsigned long long t = sm.vote[(r + 1) & 1][threadIdx.x];
-        sm.vote[(r + 1) & 1][threadIdx.x] = 0ULL;    // next added to two columns (two barriers) from now
+        sm.vote[r & 1][threadIdx.x] = 0ULL;          // the OTHER buffer: read by everybody a column ago, added to again after the next barrier
         PShard *sh = a.vote + (size_t)((r + 4) % 3) * NSHARD + (blockIdx.x % NSHARD);
         __hip_atomic_fetch_add(&sh->word[threadIdx.x], t + PRK_BIAS + PRK_TICKET, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
@@ -498,10 +547,10 @@ __global__ __launch_bounds__((CpCfg<W, K>::MAXT > 0 ? CpCfg<W, K>::MAXT : 64)) v
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   };
-  // The table rows of a column depend only on the base stream: they are fetched at the end of the previous column,
-  // ahead of the vote exchange, so that their LDS latency never sits in front of the band.
-  int T[C + 1];
-  if (live) lookups(T);
+  unsigned AE[NA], AO[NA];
+  static_for([&](auto kc) __attribute__((always_inline)) { constexpr int k = decltype(kc)::value; AE[k] = 0; AO[k] = 0; },
+             std::make_integer_sequence<int, NA>{});
+  if (live) window_words(AE, AO);
   // ---- column -1: boundary row (ram_extend.c:909-946) and the candidates of row 0 -----------------
   if (a.L > 0)
   {
@@ -518,9 +567,9 @@ __global__ __launch_bounds__((CpCfg<W, K>::MAXT > 0 ? CpCfg<W, K>::MAXT : 64)) v
         v = (j < B) ? v : SENT;                                    // dead cells: sentinel
         m[i] = v; e[i] = v + a.ge;                                 // e = max(sub + go, gap) + ge with go <= 0
       }, std::make_integer_sequence<int, C>{});
-      cp_reduce<W, K, true>(ln, T, m, e, bestF, jb, bestA);
+      cp_reduce<W, K, true>(ln, sm.tabs, AE, AO, m, e, bestF, jb, bestA);
       finish_column(bestA, contrib);
-      lookups(T);
+      window_words(AE, AO);
     }
     publish(-1, contrib);
   }
@@ -530,10 +579,50 @@ __global__ __launch_bounds__((CpCfg<W, K>::MAXT > 0 ? CpCfg<W, K>::MAXT : 64)) v
   // One column.  The fast and the masked variant are two separate loops below (a wave switches between them when its
   // flanks enter or leave the band's range): with both variants in ONE loop body the register allocator needed ~45
   // registers more than the larger of the two.  Returns true when the column loop ends.
+  // the band of one row against winner b: row r from row r-1, best cell of row r, best cells of the candidate rows r+1
+  auto band = [&](const int r, const int b, auto gc, int &bestF, int &jb, int (&bestA)[4]) __attribute__((always_inline))
+  {
+    constexpr bool G = decltype(gc)::value;
+    int sFv[C];
+    winner_scores(AE, AO, b, sFv);
+    cp_update<W, K, G>(ln, vgo, vge, a.go + (r + 1) * a.ge /* edge fill, first W rows only (set_masks: iWr) */, sFv, m, e);
+    CP_TICK(2);                  // row update
+    cp_reduce<W, K, G>(ln, sm.tabs, AE, AO, m, e, bestF, jb, bestA);
+    CP_TICK(3);                  // reductions
+  };
   auto column = [&](const int r, auto gc) __attribute__((always_inline)) -> bool
   {
     constexpr bool G = decltype(gc)::value;
+    // Speculation (device-wide mode, blocks of up to 11 cells): the vote of row r needs two trips through the memory
+    // fabric; meanwhile the workgroup computes row r against ITS OWN argmax of the candidate sums (the sums it forwarded a
+    // moment ago).  When the device-wide vote agrees -- nearly always while the flanks still align -- the row is done when
+    // the vote arrives; otherwise the saved row r-1 is restored and the band runs again with the true winner.
+    constexpr bool SPEC = DEV && C <= 11;
     CP_TICK(7);                  // barrier released .. loop top
+    int bestA[4] = { 0, 0, 0, 0 }, bestF = 0, jb = 0, guess = -1;
+    int sm_[SPEC ? C : 1], se_[SPEC ? C : 1];
+    if (G && live) set_masks(r);
+    if constexpr (SPEC)
+    {
+      // prediction: argmax of this workgroup's partial sums for row r, same tie rule as the vote
+      const unsigned long long *ps = sm.vote[r & 1];
+      unsigned long long cbest = 0;
+      guess = 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+      {
+        const unsigned long long v = ps[k];
+        const unsigned long long vk = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
+                                      (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+        if (vk > cbest) { cbest = vk; guess = k; }
+      }
+      if (live)
+      {
+        static_for([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value; sm_[i] = m[i]; se_[i] = e[i]; },
+                   std::make_integer_sequence<int, C>{});
+        band(r, guess, gc, bestF, jb, bestA);
+      }
+    }
     if (DEV)
     {
       wait_vote(r);
@@ -580,23 +669,22 @@ __global__ __launch_bounds__((CpCfg<W, K>::MAXT > 0 ? CpCfg<W, K>::MAXT : 64)) v
     CP_TICK(0);                  // vote read, stop rule
     if (live)
     {
-      int bestA[4], bestF, jb;
-      int edgeFx = 0;
-      if (G)
+      if constexpr (!SPEC) band(r, besta, gc, bestF, jb, bestA);
+      else if (guess != besta)
       {
-        set_masks(r);
-        edgeFx = a.go + (r + 1) * a.ge;                          // used in the first W rows only (set_masks: iWr)
+        static_for([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value; m[i] = sm_[i]; e[i] = se_[i]; },
+                   std::make_integer_sequence<int, C>{});
+        band(r, besta, gc, bestF, jb, bestA);
+#ifdef RAMX_CP_TIMING
+        tsum[6] += 1;            // mispredicted columns
+#endif
       }
-      cp_update<W, K, G>(ln, vgo, vge, 8 * besta, edgeFx, T, m, e);
-      CP_TICK(2);                // row update
-      cp_reduce<W, K, G>(ln, T, m, e, bestF, jb, bestA);
-      CP_TICK(3);                // reductions
       if (bestF > high) { high = bestF; pos = r + jb - W; }      // ram_extend.c:1140-1150
       if (new_max) { thigh = high; tpos = pos; }                 // :1203-1207
       finish_column(bestA, contrib);
-      lookups(T);                // next column's table rows
+      window_words(AE, AO);      // next column's window
     }
-    CP_TICK(4);                  // records, contributions, window slide, next lookups issued
+    CP_TICK(4);                  // records, contributions, window slide, next window
     if (stopped || r == a.L - 1) return true;
     publish(r, contrib);
     CP_TICK(5);                  // wave sum, LDS atomics, barrier
