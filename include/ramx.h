@@ -96,9 +96,9 @@ void ramx_set_runtime(int verbose, int when_to_stop, int l);
 /* Drop-in for reference extend_alignment (ram_extend.h:9-13, ram_extend.c:859-1258): same
  * arguments, same return value (max_extension_score_row_idx + 1), same side effects on
  * master[], coreAlign[*].{left,right}ExtensionLen and .score, same stdout lines at VERBOSE<10.
- * `score` (the reference's int**** DP state) is ignored: state lives in HBM.  pathStringFile
- * (-outmat) must be NULL: the per-cell path dump is not produced by the device path and the
- * call exits(1) with a message if it is requested. */
+ * `score` (the reference's int**** DP state) is ignored: state lives in HBM.  With pathStringFile
+ * (-outmat) the direction runs one column launch at a time and the reference's trace lines
+ * (ram_extend.c:1122-1132) are written from the device's per-cell path codes. */
 int ramx_extend_alignment(int direction, struct coreAlignment *coreAlign, int ****score,
                           struct sequenceLibrary *seqLib, char *master, int BANDWIDTH,
                           int CAPPENALTY, int MINIMPROVEMENT, int L, int N,
@@ -207,6 +207,15 @@ int ramx_dev_peek_state(ramx_dev *d, int32_t flank, int32_t *cells, int32_t *hig
  * ramx_dev_peek_state.  `flank` indexes the (padded) flank array of that call; d == NULL means the process-wide
  * session that seam 1 (ramx_extend_flat / ramx_extend_batch) runs on. */
 int ramx_dev_peek_family_state(ramx_dev *d, int32_t flank, int32_t *cells);
+
+/* -outmat support (reference ram_extend.c:1122-1132, bnw_extend.c:1027-1044): with a trace callback set, a direction runs
+ * one column launch at a time and hands every executed row to the callback: the winning base, and per flank (in flank
+ * order) the path code of each band cell (0: the substitution holds the cell's score, 1: the deletion, 2: the insertion),
+ * the row's best score and its sequence index (row + offset).  d == NULL: the process-wide session of seam 1.  A
+ * debugging aid: slow by construction.  cb == NULL switches it off. */
+typedef void (*ramx_row_trace_cb)(int32_t row, int32_t besta, const int8_t *codes /* [n_flanks][2W+1] */,
+                                  const int32_t *best_score, const int32_t *best_idx, void *user);
+int ramx_dev_set_row_trace(ramx_dev *d, ramx_row_trace_cb cb, void *user);
 
 /* Batch mode (no counterpart in the reference, whose wrapper util/extend-stk.pl:242-371 starts one
  * RAMExtend process per family): many families in ONE launch, one workgroup per family, every family with its own

@@ -458,7 +458,7 @@ static void print_loop_lines(int direction, int N, int verbose, int when_to_stop
 static int run_batch(struct cli_opts *o, time_t t_start)
 {
   const int L = o->L, l = 1;
-  if (o->outmat != NULL) { fprintf(stderr, "RAMExtend(ramx): -outmat is not available on the device path\n"); exit(1); }
+  if (o->outmat != NULL) { fprintf(stderr, "RAMExtend(ramx): -outmat traces one family; it cannot be combined with -batch\n"); exit(1); }
   FILE *lf = fopen(o->batch_file, "r");
   if (!lf) { fprintf(stderr, "Could not open batch list %s\n", o->batch_file); exit(1); }
   size_t cap = 64, F = 0;
@@ -641,10 +641,14 @@ int ramx_cli_main(int argc, char **argv)
   struct coreAlignment *cores = NULL;
   int N = 0;
   struct sequenceLibrary *lib = ramx_load_sequence_subset_minimal(o.seq_file, o.ranges_file, &cores, &N, L + o.bandwidth);
-  if (o.outmat != NULL)
+  FILE *fp_mat = NULL;
+  if (o.outmat != NULL)       /* ram_extend.c:384-390 */
   {
-    fprintf(stderr, "RAMExtend(ramx): -outmat (per-cell DP path dump) is not available on the device path\n");
-    exit(1);
+    if ((fp_mat = fopen(o.outmat, "w")) == NULL)
+    {
+      fprintf(stderr, "Could not create the output matrix file %s\n", o.outmat);
+      exit(1);
+    }
   }
   phase_done("load");
   print_header(&o, o.ranges_file, N, lib);
@@ -656,15 +660,16 @@ int ramx_cli_main(int argc, char **argv)
   fflush(stdout);
   warm_join();
   phase_done("device ready");
-  int rightbp = ramx_extend_alignment(1, cores, NULL, lib, master, o.bandwidth, o.cappenalty, o.minimprovement, L, N, o.sp, NULL);
+  int rightbp = ramx_extend_alignment(1, cores, NULL, lib, master, o.bandwidth, o.cappenalty, o.minimprovement, L, N, o.sp, fp_mat);
   printf("Extended right: %d bp\n", rightbp);
   phase_done("extend right");
   ramx_overlap_avoidance(cores, lib);
   phase_done("overlap avoidance");
-  int leftbp = ramx_extend_alignment(0, cores, NULL, lib, master, o.bandwidth, o.cappenalty, o.minimprovement, L, N, o.sp, NULL);
+  int leftbp = ramx_extend_alignment(0, cores, NULL, lib, master, o.bandwidth, o.cappenalty, o.minimprovement, L, N, o.sp, fp_mat);
   printf("Extended left : %d bp\n", leftbp);
   phase_done("extend left");
   write_results(&o, cores, lib, master, rightbp, leftbp, o.cons_file, o.outtsv, o.outfa);
+  if (fp_mat != NULL) fclose(fp_mat);     /* ram_extend.c:778-779 */
   phase_done("report + outputs");
 
   const double duration = difftime(time(0), t_start);

@@ -42,6 +42,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#include <vector>
 
 
 #include "ramx_kernels_common.h"
@@ -114,6 +115,8 @@ struct ramx_dev
   PeerBox *devbox;     // this rank's fine-grained device-memory box (exported over hipIpc)
   hipStream_t cls_stream[RAMX_NGROUP]; hipEvent_t cls_ready, cls_done[RAMX_NGROUP]; int cls_init;   // batch mode: one stream per workgroup shape
   int force_chain;   // RAMX_FORCE_CHAIN=1: always run the full candidate recurrence (test hook)
+  ramx_row_trace_cb trace_cb; void *trace_user;   // -outmat: per-row trace (forces the per-column launches)
+  signed char *d_dbg_codes; int2 *d_dbg_best; size_t cap_dbg_codes, cap_dbg_best;
   int cp_flanks_ok;    // begin_direction: every flank is empty or has t_lo <= 0 (what the cell-parallel kernels take)
   int2 *d_cpstate; size_t cap_cpstate; int cpstate_W, cpstate_n;   // RAMX_CP_PEEK=1: final rows of the cell-parallel kernel (tests)
 };
@@ -186,7 +189,7 @@ extern "C" void ramx_dev_destroy(ramx_dev *d)
     (void)hipEventDestroy(d->cls_ready);
   }
   if (d->devbox) (void)hipFree(d->devbox);
-  (void)hipFree(d->d_fam); (void)hipFree(d->d_famctl); (void)hipFree(d->d_cpstate);
+  (void)hipFree(d->d_fam); (void)hipFree(d->d_famctl); (void)hipFree(d->d_cpstate); (void)hipFree(d->d_dbg_codes); (void)hipFree(d->d_dbg_best);
   if (d->hostbox_mirror) (void)hipFree(d->hostbox_mirror);
   if (d->d_peer) (void)hipFree(d->d_peer);
   for (int i = 0; i < 2; i++) if (d->ev_chk[i]) (void)hipEventDestroy(d->ev_chk[i]);
@@ -290,6 +293,17 @@ static void launch_column(ramx_dev *d, const KArgs &a)
     hipLaunchKernelGGL((ramx_column_kernel<INIT, false, 256>), grid, block, 0, d->stream, a);
   else
     hipLaunchKernelGGL((ramx_column_kernel<INIT, true, 256>), grid, block, 0, d->stream, a);
+}
+
+// -outmat trace: the DBG instantiation also writes the per-cell path codes and the row's best cell of every flank
+static void launch_column_trace(ramx_dev *d, const KArgs &a)
+{
+  const int tiles = d->Np / 64;
+  const dim3 grid((tiles + 3) / 4), block(256);
+  if (a.go <= 0 && a.ge <= 0 && !d->force_chain)
+    hipLaunchKernelGGL((ramx_column_kernel<false, false, 256, true>), grid, block, 0, d->stream, a);
+  else
+    hipLaunchKernelGGL((ramx_column_kernel<false, true, 256, true>), grid, block, 0, d->stream, a);
 }
 
 // ---- host-side collective on 4 x int64 in device memory (RCCL, or the test hook) ---------------
@@ -957,7 +971,8 @@ extern "C" int ramx_dev_run_direction(ramx_dev *d, ramx_run_info *info)
   bool persistent = false;
   // ---- cell-parallel route (single GPU): K lanes per flank, the whole direction in one cooperative launch of at most one
   // workgroup per CU; boundary row and every column inside the kernel ---------------------------------------------------
-  if (!multi && d->cp_flanks_ok && !d->force_chain && L > 0 && d->Nx > 0 && getenv("RAMX_NO_PERSISTENT") == NULL &&
+  const bool tracing = d->trace_cb != NULL;
+  if (!tracing && !multi && d->cp_flanks_ok && !d->force_chain && L > 0 && d->Nx > 0 && getenv("RAMX_NO_PERSISTENT") == NULL &&
       getenv("RAMX_NO_CP_DEVICE") == NULL && ramx_cp_max_family(a.W, a.go, a.ge, d->tab, L) > 0)
   {
     int dev = 0, cus = 0, k = 0, th = 0, nb = 0;
@@ -1005,7 +1020,7 @@ extern "C" int ramx_dev_run_direction(ramx_dev *d, ramx_run_info *info)
     // the in-place row buffer holds S(-1) after K(-1); d_ctl[1] holds the initial control block, the persistent
     // kernel writes its final one to d_ctl[0]
     if (d->d_state[0] != d->d_state[1]) { ramx_set_error("persistent path needs the in-place row buffer"); }
-    else
+    else if (!tracing)
     {
       prk_local_rc = prk_run(d, a, L, &persistent);
       // Single GPU: a failure is simply returned.  Multi-rank: once the ranks have agreed on the persistent path
@@ -1081,6 +1096,36 @@ extern "C" int ramx_dev_run_direction(ramx_dev *d, ramx_run_info *info)
     a.r = r; a.S_in = d->d_state[(r + 1) & 1]; a.S_out = d->d_state[r & 1];
     a.ctl_in = d->d_ctl + ((r + 1) & 1); a.ctl_out = d->d_ctl + (r & 1);
     a.sums_out = slot(r + 1); a.sums_zero = slot(r + 2);
+    if (tracing)
+    {
+      // one row at a time: launch, wait, hand the row's trace to the caller (debugging aid, no attempt at speed)
+      const int B = 2 * a.W + 1;
+      int trc;
+      if ((trc = ensure(&d->d_dbg_codes, &d->cap_dbg_codes, (size_t)d->Np * B)) != RAMX_OK) return trc;
+      if ((trc = ensure(&d->d_dbg_best, &d->cap_dbg_best, (size_t)d->Np * sizeof(int2))) != RAMX_OK) return trc;
+      a.dbg_codes = d->d_dbg_codes; a.dbg_best = d->d_dbg_best;
+      launch_column_trace(d, a);
+      launches++;
+      HIPCHK(hipGetLastError());
+      HIPCHK(hipStreamSynchronize(d->stream));
+      RamxCtl c;
+      HIPCHK(hipMemcpy(&c, a.ctl_out, sizeof(c), hipMemcpyDeviceToHost));
+      if (c.rows_done == r + 1)      // the launch ran (a stopped predecessor makes the kernel return at once)
+      {
+        std::vector<int8_t> codes((size_t)d->Nx * B + 1);
+        std::vector<int2> best((size_t)d->Nx + 1);
+        std::vector<int32_t> bs((size_t)d->Nx + 1), bi((size_t)d->Nx + 1);
+        if (d->Nx)
+        {
+          HIPCHK(hipMemcpy(codes.data(), d->d_dbg_codes, (size_t)d->Nx * B, hipMemcpyDeviceToHost));
+          HIPCHK(hipMemcpy(best.data(), d->d_dbg_best, (size_t)d->Nx * sizeof(int2), hipMemcpyDeviceToHost));
+        }
+        for (int i = 0; i < d->Nx; i++) { bs[i] = best[i].x; bi[i] = best[i].y; }
+        d->trace_cb(r, c.besta, codes.data(), bs.data(), bi.data(), d->trace_user);
+      }
+      if (c.stopped) stopped = true;
+      continue;
+    }
     const bool sample = (r % stride) == (stride / 2) && nsamp < MAX_SAMPLES;
     if (sample) HIPCHK(hipEventRecord(d->ev_s0[nsamp], d->stream));
     launch_column<false>(d, a);
@@ -1188,6 +1233,15 @@ extern "C" int ramx_dev_peek_family_state(ramx_dev *d, int32_t flank, int32_t *c
   HIPCHK(hipSetDevice(d->ordinal));
   const int B = 2 * d->cpstate_W + 1;
   HIPCHK(hipMemcpy(cells, d->d_cpstate + (size_t)flank * B, (size_t)B * sizeof(int2), hipMemcpyDeviceToHost));
+  return RAMX_OK;
+}
+
+extern "C" int ramx_dev_set_row_trace(ramx_dev *d, ramx_row_trace_cb cb, void *user)
+{
+  if (!d) d = ramx_default_device();
+  if (!d) return RAMX_ERR_NO_DEVICE;
+  d->trace_cb = cb;
+  d->trace_user = user;
   return RAMX_OK;
 }
 

@@ -6,6 +6,7 @@
  * interval), hands the flanks to the device layer (ramx_device.hip), and writes the results back
  * into master[] and the cores exactly where the reference does.  No DP arithmetic happens here.
  */
+#include <ctype.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -76,6 +77,52 @@ ramx_dev *ramx_default_device(void)
     if (ramx_dev_create(ord, &g_dev) != RAMX_OK) g_dev = NULL;
   }
   return g_dev;
+}
+
+/* ---- -outmat: the reference's per-row trace (ram_extend.c:1122-1132, bnw_extend.c:1027-1044) -------------------------
+ * written from what the device reports for every executed row: per band cell which state holds the cell's score, per
+ * flank the row's best score and index.  The characters themselves come from the caller's library. */
+struct trace_ctx
+{
+  FILE *out;
+  int direction, W, nx;
+  const int32_t *core_index;      /* flank -> position of its core in the list (the reference's n) */
+  const ramx_flank *flanks;
+  const ramx_flat_cores *cores;
+  const int8_t *sequence;
+};
+static FILE *g_trace_file = NULL;
+
+static char trace_num_to_char(int8_t z)      /* sequence.c:1091-1111 */
+{
+  static const char t[8] = { 'A', 'C', 'G', 'T', 'a', 'c', 'g', 't' };
+  return (z >= 0 && z < 8) ? t[z] : 'N';
+}
+
+static void trace_row(int32_t row, int32_t besta, const int8_t *codes, const int32_t *best_score, const int32_t *best_idx, void *user)
+{
+  const struct trace_ctx *t = (const struct trace_ctx *)user;
+  const int W = t->W, B = 2 * W + 1;
+  char *path = (char *)malloc((size_t)B + 1);
+  for (int i = 0; i < t->nx; i++)
+  {
+    const ramx_flank *f = &t->flanks[i];
+    const int n = t->core_index[i];
+    for (int j = 0; j < B; j++)
+    {
+      /* bnw_extend.c:1029-1031: the base as stored (not complemented), 'X' outside the flank */
+      const int64_t tt = (int64_t)(j - W) + row;
+      const int64_t p = f->start + (int64_t)f->step * tt;
+      char base = 'X';
+      if (p >= 0 && p >= t->cores->lower[n] && p <= t->cores->upper[n]) base = trace_num_to_char(t->sequence[p]);
+      const int c = codes[(size_t)i * B + j];
+      path[j] = c == 0 ? base : (c == 1 ? '-' : (char)tolower((unsigned char)base));
+    }
+    path[2 * W] = '\0';                              /* ram_extend.c:1123: the last cell is cut off */
+    fprintf(t->out, "dir=%s:n=%d:row=%d: %s best:score=%d:offset=%d:cons=%c\n", t->direction ? "right" : "left", n, row, path,
+            best_score[i], best_idx[i] - row + W, trace_num_to_char((int8_t)besta));
+  }
+  free(path);
 }
 
 static double wall_ms(void)
@@ -158,7 +205,14 @@ int ramx_extend_flat(int direction, ramx_flat_cores *c, const int8_t *sequence, 
   const int nx = ramx_resolve_flanks(direction, c, W, L, fl, map);
   int8_t *cons = (int8_t *)malloc((size_t)L + 16);
   int32_t *th, *tp;
-  if (nx > 0 && nx <= 512 && L > 0 && W >= 1 && getenv("RAMX_NO_FAMILY_ROUTE") == NULL)
+  struct trace_ctx tctx;
+  if (g_trace_file != NULL)
+  {
+    tctx.out = g_trace_file; tctx.direction = direction; tctx.W = W; tctx.nx = nx; tctx.core_index = map; tctx.flanks = fl;
+    tctx.cores = c; tctx.sequence = sequence;
+    ramx_dev_set_row_trace(d, trace_row, &tctx);
+  }
+  if (g_trace_file == NULL && nx > 0 && nx <= 512 && L > 0 && W >= 1 && getenv("RAMX_NO_FAMILY_ROUTE") == NULL)
   {
     /* a family that fits one workgroup needs no device-wide barrier: run it as a batch of one (block-local vote) */
     const int npad = (nx + 63) & ~63;
@@ -178,6 +232,7 @@ int ramx_extend_flat(int direction, ramx_flat_cores *c, const int8_t *sequence, 
     rc = ramx_dev_begin_direction(d, fl, nx, p);
     info->prep_ms = wall_ms() - t0;
     if (rc == RAMX_OK) rc = ramx_dev_run_direction(d, info);
+    if (g_trace_file != NULL) ramx_dev_set_row_trace(d, NULL, NULL);
     if (rc != RAMX_OK) { free(cons); free(map); free(fl); return rc; }
     th = (int32_t *)malloc(sizeof(int32_t) * (nx > 0 ? nx : 1));
     tp = (int32_t *)malloc(sizeof(int32_t) * (nx > 0 ? nx : 1));
@@ -213,11 +268,7 @@ int ramx_extend_alignment(int direction, struct coreAlignment *coreAlign, int **
                           struct scoringSystem *scoreParams, FILE *pathStringFile)
 {
   (void)score;
-  if (pathStringFile != NULL)
-  {
-    fprintf(stderr, "RAMExtend(ramx): -outmat (per-cell path dump) is not available on the device path\n");
-    exit(1);
-  }
+  g_trace_file = pathStringFile;          /* -outmat: ramx_extend_flat runs the direction row by row and writes the trace */
   if (g_verbose >= 3)   /* ram_extend.c:886-892 */
   {
     if (direction) printf("extend_alignment(right): Called with %d edges\n", N);
@@ -297,6 +348,7 @@ int ramx_extend_alignment(int direction, struct coreAlignment *coreAlign, int **
     cc->score = fc.score[k];
   }
   free(i64); free(i8); free(i32); free(mflat);
+  g_trace_file = NULL;
   return ret;
 }
 

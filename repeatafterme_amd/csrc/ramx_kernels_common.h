@@ -39,6 +39,10 @@ struct KArgs
   signed char *cons_out;
   int Np, Nx, W, r, go, ge, cap, minimp, when_to_stop, nshards_in;
   int tab[RAMX_NCLASS][4];   // tab[class][candidate] = matrix[candidate][class]
+  // -outmat trace (DBG instantiation of the column kernel only): per cell which state holds the cell's score
+  // (0 substitution, 1 deletion, 2 insertion: bnw_extend.c:1027-1044), per flank the row's best score and cell
+  signed char *dbg_codes;    // [Np][2W+1]
+  int2 *dbg_best;            // [Np]
 };
 
 struct FamDesc { int tile0, ntiles, nx, id; };      // first 64-flank tile, tiles, flanks of the family; its index in the caller's arrays
@@ -216,9 +220,9 @@ __device__ __forceinline__ StepT fetch_step(const int *s_tab, unsigned bc, bool 
 // !FIN (virtual step j == B): only the candidates' last cell.  INIT: row "r" is the boundary row
 // (ram_extend.c:909-946).  OOB = false is the fast path taken by a wave whose 64 flanks all cover the whole
 // band of both rows: no bounds selects at all.
-template <bool INIT, bool FIN, bool OOB, bool CHAIN>
+template <bool INIT, bool FIN, bool OOB, bool CHAIN, bool DBG = false>
 __device__ __forceinline__ void band_step(const int go, const int ge, const int W, const StepU u, const StepT t,
-                                          const int Pm, const int PeNext, LaneDP &L, int &outM, int &outE)
+                                          const int Pm, const int PeNext, LaneDP &L, int &outM, int &outE, signed char *code = nullptr)
 {
   int eCn, m = 0;
   if (FIN)
@@ -241,6 +245,13 @@ __device__ __forceinline__ void band_step(const int go, const int ge, const int 
       }
     }
     m = imax(sub, gap);                            // :1015-1018
+    if (DBG && !INIT)
+    {
+      // which state the reference's path string reports for this cell (:1038-1043): the substitution if it holds the
+      // cell's score, else the deletion if it does, else the insertion; out-of-bounds cells have all three equal
+      const int del = (OOB && !t.inb) ? u.vF : PeNext;
+      code[u.j] = (signed char)((sub == m) ? 0 : ((del == m) ? 1 : 2));
+    }
     if (!INIT)
     {
       const bool better = m > L.bestF;             // :1020-1024 strict >: lowest offset wins ties
@@ -300,10 +311,10 @@ __device__ __forceinline__ void band_step(const int go, const int ge, const int 
 }
 
 // The whole band of one flank (one lane) for column r: streams S(r-1) in, S(r) out.
-template <bool INIT, bool OOB, bool CHAIN>
+template <bool INIT, bool OOB, bool CHAIN, bool DBG = false>
 __device__ __forceinline__ void run_band(const KArgs &a, const int r, const int *s_tab, const int4 *Sin, int4 *Sout,
                                          const unsigned *bp, const int jlo, const int jhi, LaneDP &D, int &high, int &pos,
-                                         int4 (&buf)[PF], int4 (&far)[PF], unsigned w0, unsigned w1, unsigned w2)
+                                         int4 (&buf)[PF], int4 (&far)[PF], unsigned w0, unsigned w1, unsigned w2, signed char *code = nullptr)
 {
   const int W = a.W, B = 2 * W + 1, Q = W + 1, go = a.go, ge = a.ge;
   // OOB fill values (bnw_extend.c:990-1002): uniform per (row, cell)
@@ -334,8 +345,8 @@ __device__ __forceinline__ void run_band(const KArgs &a, const int r, const int 
   // One regular slot q = (m,e) of cells 2q and 2q+1 of row r; candidate cells 2q-1 and 2q of row r+1.
   auto regular_slot = [&](int q, int4 cur, int4 nxt, const StepT &t0, const StepT &t1) {
     int m0, e0, m1, e1;
-    band_step<INIT, true, OOB, CHAIN>(go, ge, W, make_u(2 * q), t0, cur.x, cur.w, D, m0, e0);
-    band_step<INIT, true, OOB, CHAIN>(go, ge, W, make_u(2 * q + 1), t1, cur.z, nxt.y, D, m1, e1);
+    band_step<INIT, true, OOB, CHAIN, DBG>(go, ge, W, make_u(2 * q), t0, cur.x, cur.w, D, m0, e0, code);
+    band_step<INIT, true, OOB, CHAIN, DBG>(go, ge, W, make_u(2 * q + 1), t1, cur.z, nxt.y, D, m1, e1, code);
 #if defined(RAMX_DBG_NOMEM) || defined(RAMX_DBG_NOSTORE)
     if (m0 == 0x7fffffff) Sout[(size_t)q * 64] = make_int4(m0, e0, m1, e1);
 #else
@@ -345,7 +356,7 @@ __device__ __forceinline__ void run_band(const KArgs &a, const int r, const int 
   auto final_slot = [&](int4 cur, const StepT &t0, const StepT &t1) {
     int m0, e0, m1, e1;
     // cell B-1 has no deletion predecessor (bnw_extend.c:892); then the virtual step j = B
-    band_step<INIT, true, OOB, CHAIN>(go, ge, W, make_u(2 * W), t0, cur.x, NEG, D, m0, e0);
+    band_step<INIT, true, OOB, CHAIN, DBG>(go, ge, W, make_u(2 * W), t0, cur.x, NEG, D, m0, e0, code);
     band_step<INIT, false, OOB, CHAIN>(go, ge, W, make_u(B), t1, 0, 0, D, m1, e1);
     if (!INIT)
     {

@@ -4,7 +4,7 @@
 
 #include "ramx_kernels_common.h"
 
-template <bool INIT, bool CHAIN, int BLOCK>
+template <bool INIT, bool CHAIN, int BLOCK, bool DBG = false>
 __global__ __launch_bounds__(BLOCK) void ramx_column_kernel(const KArgs a)
 {
   constexpr int WPB = BLOCK / 64;
@@ -107,9 +107,11 @@ __global__ __launch_bounds__(BLOCK) void ramx_column_kernel(const KArgs a)
     for (int c = 0; c < 4; c++) { D.eA[c] = NEG; D.bestA[c] = NEG; }
     int high = 0, pos = 0;
     // wave-uniform choice: do all 64 flanks cover every cell of both rows?  (steps 0..B)
-    const bool all_in = !INIT && __all((n >= a.Nx) || ((jlo <= 0) && (jhi >= B)));   // padding lanes: all-N stream, masked vote
+    const bool all_in = !INIT && !DBG && __all((n >= a.Nx) || ((jlo <= 0) && (jhi >= B)));   // padding lanes: all-N stream, masked vote
     if (all_in) run_band<INIT, false, CHAIN>(a, r, s_tab, Sin, Sout, bp, jlo, jhi, D, high, pos, buf, far, w0, w1, w2);
-    else run_band<INIT, true, CHAIN>(a, r, s_tab, Sin, Sout, bp, jlo, jhi, D, high, pos, buf, far, w0, w1, w2);
+    else run_band<INIT, true, CHAIN, DBG>(a, r, s_tab, Sin, Sout, bp, jlo, jhi, D, high, pos, buf, far, w0, w1, w2,
+                                          DBG ? a.dbg_codes + (size_t)n * B : nullptr);
+    if (DBG && !INIT) a.dbg_best[n] = make_int2(D.bestF, r + D.jbest - W);   // best_row_score, *max_score_sequence_idx
     if (INIT || new_max) a.trim[n] = make_int2(high, pos);   // ram_extend.c:1203-1207 (913-914 at init)
     if (n < a.Nx)
     {

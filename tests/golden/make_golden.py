@@ -69,6 +69,28 @@ def run_cli(case, stem, argv):
     open(os.path.join(out, "argv"), "w").write(" ".join(argv) + "\n")
 
 
+# cases whose -outmat trace (one line per extendable core and executed row: path string, best score, offset, base;
+# ram_extend.c:1122-1132) is kept as well, gzip-compressed
+OUTMAT_CASES = ["t2_default", "t2_w40_14p", "t2_L100", "g0_w40_14p", "g1_rs", "g2_w3", "g3_w20_14p", "ov_w40"]
+
+
+def outmat_traces():
+    import gzip
+    import tempfile
+    for case, stem, argv in CLI_CASES:
+        if case not in OUTMAT_CASES:
+            continue
+        with tempfile.TemporaryDirectory() as td:
+            mat = os.path.join(td, "mat")
+            cmd = [po.REF_CLI, "-twobit", f"inputs/{stem}.2bit", "-ranges", f"inputs/{stem}.tsv", "-outmat", mat] + argv
+            r = subprocess.run(cmd, cwd=HERE, capture_output=True, text=True)
+            assert r.returncode == 0, (cmd, r.stderr)
+            data = open(mat, "rb").read()
+        with gzip.GzipFile(os.path.join(HERE, "cli", case, "outmat.gz"), "wb", mtime=0) as fh:
+            fh.write(data)
+        print("outmat", case, data.count(b"\n"), "lines")
+
+
 def api_vectors():
     """Reference results for in-memory sets (adversarial + two uniform families)."""
     data = {}
@@ -131,6 +153,7 @@ def main():
     for case, stem, argv in CLI_CASES:
         run_cli(case, stem, argv)
         print("cli case", case)
+    outmat_traces()
     api_vectors()
 
 

@@ -44,6 +44,32 @@ def test_cli_matches_reference_outputs(case, tmp_path):
             assert not os.path.exists(tmp_path / f) or f != "cons"
 
 
+OUTMAT = [c for c in CASES if os.path.exists(os.path.join(G, "cli", c, "outmat.gz"))]
+
+
+@pytest.mark.parametrize("case", OUTMAT)
+def test_cli_outmat_trace_matches_reference(case, tmp_path):
+    """-outmat: one line per extendable core and executed row -- the path string of the band (which state holds each
+    cell's score), the row's best score, its offset and the consensus base (ram_extend.c:1122-1132,
+    bnw_extend.c:1027-1044) -- byte-identical to the reference binary's file, with the ordinary outputs unchanged."""
+    import gzip
+    argv = open(os.path.join(G, "cli", case, "argv")).read().split()
+    stem = STEM[case.split("_")[0]]
+    cmd = [_lib.CLI_PATH, "-twobit", f"inputs/{stem}.2bit", "-ranges", f"inputs/{stem}.tsv", "-cons", str(tmp_path / "cons"),
+           "-outtsv", str(tmp_path / "tsv"), "-outfa", str(tmp_path / "fa"), "-outmat", str(tmp_path / "mat")] + argv
+    r = subprocess.run(cmd, cwd=G, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    want = gzip.open(os.path.join(G, "cli", case, "outmat.gz"), "rb").read().decode().splitlines()
+    got = open(tmp_path / "mat").read().splitlines()
+    assert len(got) == len(want), (len(got), len(want))
+    for k, (a, b) in enumerate(zip(got, want)):
+        assert a == b, f"line {k}: {a!r} != {b!r}"
+    for f in ("tsv", "fa"):
+        ref_f = os.path.join(G, "cli", case, f)
+        if os.path.exists(ref_f):
+            assert open(tmp_path / f).read() == open(ref_f).read(), f
+
+
 def test_cli_version_and_usage():
     r = subprocess.run([_lib.CLI_PATH, "-version"], capture_output=True, text=True)
     assert r.returncode == 0 and r.stdout.startswith("RAMExtend Version 0.0.7 - build ")
