@@ -476,17 +476,37 @@ int ramx_extend_batch(int direction, ramx_family *fam, int32_t F, const ramx_par
   return rc;
 }
 
-/* bnw_extend.c:87-155 -- kept for link compatibility; the device path never reads it, so a single
- * zeroed block with the same index shape is enough (and avoids 2*N*B mallocs). */
+/* bnw_extend.c:87-155 -- kept for link compatibility: the device path never reads it.  The block has the reference's
+ * index shape score[2][num_align][2*bandwidth+1][2], so code written against the reference that dereferences it (the
+ * VERBOSE >= 12 dump of ram_extend.c:949-959, unit tests) reads zeros instead of faulting -- but every [n] shares ONE
+ * row of cells (2 * num_align * (2W+1) separate mallocs are exactly what this library exists to avoid). */
 int ****ramx_allocate_score(int num_align, int bandwidth)
 {
-  (void)bandwidth;
-  if (num_align < 1) return NULL;
-  return (int ****)calloc(2, sizeof(int ***));
+  if (num_align < 1 || bandwidth < 0) return NULL;
+  const int B = 2 * bandwidth + 1;
+  int ****score = (int ****)calloc(2, sizeof(int ***));
+  int **row = (int **)calloc((size_t)B, sizeof(int *));
+  int *cells = (int *)calloc((size_t)B * 2, sizeof(int));
+  if (!score || !row || !cells) { free(score); free(row); free(cells); return NULL; }
+  for (int j = 0; j < B; j++) row[j] = cells + 2 * j;
+  for (int ff = 0; ff < 2; ff++)
+  {
+    score[ff] = (int ***)calloc((size_t)num_align, sizeof(int **));
+    if (!score[ff]) { free(score[0]); free(score); free(row); free(cells); return NULL; }
+    for (int n = 0; n < num_align; n++) score[ff][n] = row;
+  }
+  return score;
 }
 
 void ramx_free_score(int num_align, int bandwidth, int ****score)
 {
-  (void)num_align; (void)bandwidth;
+  (void)bandwidth;
+  if (!score) return;
+  if (num_align >= 1 && score[0] && score[0][0])
+  {
+    free(score[0][0][0]);     /* the shared cells */
+    free(score[0][0]);        /* the shared row */
+  }
+  free(score[0]); free(score[1]);
   free(score);
 }
