@@ -145,6 +145,11 @@ int ramx_extend_flat(int direction, ramx_flat_cores *cores, const int8_t *sequen
  * fingerprinted.  The reference has no such state (ram_extend.c reads seqLib->sequence on every call): a caller who
  * wants to be explicit can drop the device copy with this call. */
 void ramx_invalidate_library(void);
+/* Upload a library ahead of the first extension call (e.g. from a helper thread while the caller still prints its
+ * report tables): the next ramx_extend_flat / ramx_extend_alignment calls on the same (pointer, length) use the device
+ * copy without looking at the buffer again -- the caller vouches that it does not change until
+ * ramx_invalidate_library() or a call with another buffer. */
+int ramx_preload_library(const int8_t *sequence, uint64_t seq_len);
 
 /* ------------------------------------------------------------------------------------------
  * Seam 2: thin device API (one ramx_dev per GPU / per process rank)

@@ -11,7 +11,7 @@ CLI_PATH = os.path.join(_PKG, "RAMExtend")
 
 # every symbol include/ramx.h declares (tests/test_cabi.py checks the .so exports all of them)
 EXPORTS = [
-    "ramx_set_runtime", "ramx_extend_alignment", "ramx_extend_flat", "ramx_invalidate_library", "ramx_resolve_flanks", "ramx_last_error", "ramx_device_count",
+    "ramx_set_runtime", "ramx_extend_alignment", "ramx_extend_flat", "ramx_invalidate_library", "ramx_preload_library", "ramx_resolve_flanks", "ramx_last_error", "ramx_device_count",
     "ramx_dev_create", "ramx_dev_destroy", "ramx_dev_load_library", "ramx_dev_begin_direction",
     "ramx_dev_run_direction", "ramx_dev_download", "ramx_dev_peek_state", "ramx_dev_peek_family_state", "ramx_dev_set_row_trace", "ramx_dev_run_families", "ramx_extend_batch", "ramx_comm_unique_id",
     "ramx_dev_comm_init", "ramx_dev_set_allreduce_cb", "ramx_dev_peer_export", "ramx_dev_peer_import",

@@ -183,15 +183,42 @@ static void phase_done(const char *what)
  * input, so it runs in a helper thread while the loader reads the .2bit; joined before the first extension. */
 static pthread_t g_warm_thread;
 static int g_warm_started = 0;
+/* the helper thread starts the HIP runtime while the loader works and then, as soon as the main thread hands it the
+ * library, uploads it while the main thread prints the core table (1 GB of flanks: ~60 ms that would otherwise sit in
+ * front of the right extension) */
+static pthread_mutex_t g_warm_mu = PTHREAD_MUTEX_INITIALIZER;
+static pthread_cond_t g_warm_cv = PTHREAD_COND_INITIALIZER;
+static const struct sequenceLibrary *g_warm_lib = NULL;
+static int g_warm_quit = 0;
 static void *warm_device(void *unused)
 {
   (void)unused;
   (void)ramx_default_device();          /* failure is reported by the main thread's own call later */
+  pthread_mutex_lock(&g_warm_mu);
+  while (g_warm_lib == NULL && !g_warm_quit) pthread_cond_wait(&g_warm_cv, &g_warm_mu);
+  const struct sequenceLibrary *lib = g_warm_lib;
+  pthread_mutex_unlock(&g_warm_mu);
+  if (lib != NULL) (void)ramx_preload_library((const int8_t *)lib->sequence, lib->length);   /* a failure: seam 1 uploads (and reports) itself */
   return NULL;
+}
+static void warm_offer_library(const struct sequenceLibrary *lib)
+{
+  pthread_mutex_lock(&g_warm_mu);
+  g_warm_lib = lib;
+  pthread_cond_signal(&g_warm_cv);
+  pthread_mutex_unlock(&g_warm_mu);
 }
 static void warm_join(void)
 {
-  if (g_warm_started) { g_warm_started = 0; pthread_join(g_warm_thread, NULL); }
+  if (g_warm_started)
+  {
+    g_warm_started = 0;
+    pthread_mutex_lock(&g_warm_mu);
+    g_warm_quit = 1;
+    pthread_cond_signal(&g_warm_cv);
+    pthread_mutex_unlock(&g_warm_mu);
+    pthread_join(g_warm_thread, NULL);
+  }
 }
 static void warm_start(void)
 {
@@ -651,6 +678,7 @@ int ramx_cli_main(int argc, char **argv)
     }
   }
   phase_done("load");
+  if (g_warm_started && lib != NULL && N > 0) warm_offer_library(lib);
   print_header(&o, o.ranges_file, N, lib);
   ramx_print_core_edges(cores, lib, 0, o.verbose ? 1 : 0);
   phase_done("core table");

@@ -37,6 +37,7 @@ static ramx_dev *g_dev = NULL;
 #define RAMX_FP_MAX (64ull << 20)
 static const int8_t *g_lib_ptr = NULL;
 static uint64_t g_lib_len = 0, g_lib_fp = 0;
+static int g_lib_trusted = 0;      /* ramx_preload_library: the caller vouches for the buffer until ramx_invalidate_library() */
 /* batch mode: the (pointer, length, fingerprint) of every family whose concatenation the device currently holds */
 static const int8_t **g_bl_ptr = NULL;
 static uint64_t *g_bl_len = NULL, *g_bl_fp = NULL;
@@ -64,7 +65,19 @@ static uint64_t fingerprint(const int8_t *p, uint64_t n)
 
 void ramx_invalidate_library(void)
 {
-  g_lib_ptr = NULL; g_lib_len = 0; g_lib_fp = 0; g_bl_n = 0;
+  g_lib_ptr = NULL; g_lib_len = 0; g_lib_fp = 0; g_lib_trusted = 0; g_bl_n = 0;
+}
+
+int ramx_preload_library(const int8_t *sequence, uint64_t seq_len)
+{
+  if (!sequence && seq_len) { ramx_set_error("ramx_preload_library: bad argument"); return RAMX_ERR_ARG; }
+  ramx_dev *d = ramx_default_device();
+  if (!d) return RAMX_ERR_NO_DEVICE;
+  ramx_invalidate_library();
+  const int rc = ramx_dev_load_library(d, sequence, seq_len);
+  if (rc != RAMX_OK) return rc;
+  g_lib_ptr = sequence; g_lib_len = seq_len; g_lib_fp = 0; g_lib_trusted = 1;
+  return RAMX_OK;
 }
 
 ramx_dev *ramx_default_device(void)
@@ -186,23 +199,30 @@ int ramx_extend_flat(int direction, ramx_flat_cores *c, const int8_t *sequence, 
   ramx_dev *d = ramx_default_device();
   if (!d) return RAMX_ERR_NO_DEVICE;
   const double t0 = wall_ms();
+  const int timing = getenv("RAMX_TIMING") != NULL;
+  double tph = t0;
+#define SEAM1_PHASE(name) do { if (timing) { const double t_ = wall_ms(); fprintf(stderr, "RAMX_TIMING     seam1 %-22s %8.3f ms\n", name, t_ - tph); tph = t_; } } while (0)
   const int N = c->n, W = p->bandwidth, L = p->L;
   int rc;
-  /* the library is shared by both directions: upload once per (pointer, length, content) */
+  int *map = (int *)malloc(sizeof(int) * (N > 0 ? N : 1));
+  ramx_flank *fl = (ramx_flank *)malloc(sizeof(ramx_flank) * (N > 0 ? N : 1));
+  const int nx = ramx_resolve_flanks(direction, c, W, L, fl, map);
+  SEAM1_PHASE("resolve flanks");
+  /* the library is shared by both directions: upload once per (pointer, length, content); nothing to upload when no
+   * core is extendable in this direction */
+  if (nx > 0 && !(g_lib_trusted && sequence == g_lib_ptr && seq_len == g_lib_len))
   {
     const uint64_t fp = seq_len <= RAMX_FP_MAX ? fingerprint(sequence, seq_len) : 0;
     if (sequence != g_lib_ptr || seq_len != g_lib_len || fp == 0 || fp != g_lib_fp)
     {
-      g_lib_ptr = NULL; g_lib_len = 0; g_lib_fp = 0;
-      if ((rc = ramx_dev_load_library(d, sequence, seq_len)) != RAMX_OK) return rc;
+      ramx_invalidate_library();
+      if ((rc = ramx_dev_load_library(d, sequence, seq_len)) != RAMX_OK) { free(map); free(fl); return rc; }
       g_lib_ptr = sequence;
       g_lib_len = seq_len;
       g_lib_fp = fp;
     }
   }
-  int *map = (int *)malloc(sizeof(int) * (N > 0 ? N : 1));
-  ramx_flank *fl = (ramx_flank *)malloc(sizeof(ramx_flank) * (N > 0 ? N : 1));
-  const int nx = ramx_resolve_flanks(direction, c, W, L, fl, map);
+  SEAM1_PHASE("library (hash/upload)");
   int8_t *cons = (int8_t *)malloc((size_t)L + 16);
   int32_t *th, *tp;
   struct trace_ctx tctx;
@@ -231,7 +251,9 @@ int ramx_extend_flat(int direction, ramx_flat_cores *c, const int8_t *sequence, 
   {
     rc = ramx_dev_begin_direction(d, fl, nx, p);
     info->prep_ms = wall_ms() - t0;
+    SEAM1_PHASE("begin (alloc, pack)");
     if (rc == RAMX_OK) rc = ramx_dev_run_direction(d, info);
+    SEAM1_PHASE("run direction");
     if (g_trace_file != NULL) ramx_dev_set_row_trace(d, NULL, NULL);
     if (rc != RAMX_OK) { free(cons); free(map); free(fl); return rc; }
     th = (int32_t *)malloc(sizeof(int32_t) * (nx > 0 ? nx : 1));
@@ -258,6 +280,8 @@ int ramx_extend_flat(int direction, ramx_flat_cores *c, const int8_t *sequence, 
       }
     }
   }
+  SEAM1_PHASE("download + write-back");
+#undef SEAM1_PHASE
   free(cons); free(th); free(tp); free(map); free(fl);
   return rc == RAMX_OK ? info->ret : rc;
 }
@@ -424,7 +448,7 @@ int ramx_extend_batch(int direction, ramx_family *fam, int32_t F, const ramx_par
     int32_t *tp = (int32_t *)malloc(sizeof(int32_t) * (fpos ? fpos : 1));
     if (!lib_cached)
     {
-      g_lib_ptr = NULL; g_lib_len = 0; g_lib_fp = 0; /* whatever library the device held is replaced */
+      g_lib_ptr = NULL; g_lib_len = 0; g_lib_fp = 0; g_lib_trusted = 0; /* whatever library the device held is replaced */
       rc = ramx_dev_load_library(d, lib, total_len);
       if (rc == RAMX_OK)
       {
