@@ -23,6 +23,11 @@ struct CPArgs
   struct PShard *vote;          // [3][NSHARD] ticketed vote words (zeroed by the host before the launch)
   unsigned *err;                // != 0: a bounded spin gave up
   int4 *S;                      // optional: final rows in the lane-per-flank layout (ramx_dev_peek_state), else NULL
+  // multi-GPU (flanks sharded over ranks): the mailboxes of ramx_kernels_resident.h
+  struct PeerBox *const *peers; // [nranks] every rank's box as seen from this device (NULL on one GPU)
+  struct PeerBox *box;          // this rank's own box
+  struct PeerBox *mirror;       // host-memory boxes only: device copy kept current by workgroup 0 (NULL: everybody polls `box`)
+  int rank, nranks;
 };
 
 #define RAMX_CP_NCLASS 6

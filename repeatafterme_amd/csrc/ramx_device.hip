@@ -972,38 +972,92 @@ extern "C" int ramx_dev_run_direction(ramx_dev *d, ramx_run_info *info)
   // ---- cell-parallel route (single GPU): K lanes per flank, the whole direction in one cooperative launch of at most one
   // workgroup per CU; boundary row and every column inside the kernel ---------------------------------------------------
   const bool tracing = d->trace_cb != NULL;
-  if (!tracing && !multi && d->cp_flanks_ok && !d->force_chain && L > 0 && d->Nx > 0 && getenv("RAMX_NO_PERSISTENT") == NULL &&
-      getenv("RAMX_NO_CP_DEVICE") == NULL && ramx_cp_max_family(a.W, a.go, a.ge, d->tab, L) > 0)
+  // Multi-rank: the vote crosses the devices through the mailboxes (ramx_dev_peer_* set-up), exactly as in the
+  // lane-per-flank persistent kernel; every rank must take this route or none (one agreement before, one after).
+  const bool cp_multi_ok = !multi || (d->peer_ready && d->nranks >= 2 && L < 65536 && getenv("RAMX_NO_PEER") == NULL);
+  if (!tracing && cp_multi_ok && !d->force_chain && L > 0 && getenv("RAMX_NO_PERSISTENT") == NULL && getenv("RAMX_NO_CP_DEVICE") == NULL &&
+      (multi || d->Nx > 0))
   {
     int dev = 0, cus = 0, k = 0, th = 0, nb = 0;
     HIPCHK(hipGetDevice(&dev));
     HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     const char *mx = getenv("RAMX_CP_DEVICE_MAXN");
-    if (mx == NULL || d->Nx <= atoi(mx)) ramx_cp_device_plan(a.W, d->Nx, cus, &k, &th, &nb);
+    if (d->cp_flanks_ok && ramx_cp_max_family(a.W, a.go, a.ge, d->tab, L) > 0 && (mx == NULL || d->Nx <= atoi(mx)))
+      ramx_cp_device_plan(a.W, d->Nx > 0 ? d->Nx : 1, cus, &k, &th, &nb);
+    if (multi)
+    {
+      // my mailbox is cleared BEFORE the agreement, which no remote launch can get past without my taking part
+      if (d->hostbox_host)
+      {
+        HIPCHK(hipStreamSynchronize(d->stream));
+        memset((void *)d->hostbox_host, 0, sizeof(PeerBox));
+        __sync_synchronize();
+      }
+      else HIPCHK(hipMemsetAsync(d->xbox, 0, sizeof(PeerBox), d->stream));
+      int cannot = k > 0 ? 0 : 1;
+      int arc = host_allreduce_flag(d, &cannot);
+      if (arc != RAMX_OK) return arc;
+      if (cannot) k = 0;
+    }
     if (k > 0)
     {
-      CPArgs ca;
-      memset(&ca, 0, sizeof(ca));
-      ca.bases = d->d_bases; ca.bounds = d->d_bounds; ca.trim = d->d_trim; ca.ctl_out = d->d_ctl; ca.cons_out = d->d_cons;
-      ca.Np = d->Np; ca.KW = d->KW; ca.L = L; ca.go = a.go; ca.ge = a.ge; ca.cap = a.cap; ca.minimp = a.minimp; ca.when_to_stop = a.when_to_stop;
-      memcpy(ca.tab, d->tab, sizeof(ca.tab));
-      ca.Nx = d->Nx; ca.nblocks = nb; ca.vote = d->d_vote; ca.err = d->d_err; ca.S = d->d_state[0];
-      HIPCHK(hipMemsetAsync(d->d_vote, 0, 3 * NSHARD * sizeof(PShard), d->stream));
-      HIPCHK(hipMemsetAsync(d->d_err, 0, 64, d->stream));
-      HIPCHK(hipMemsetAsync(d->d_ctl, 0, 2 * sizeof(RamxCtl), d->stream));
-      HIPCHK(hipEventRecord(d->ev_begin, d->stream));
-      int crc = ramx_cp_launch_device(d->stream, a.W, k, th, nb, ca);
-      if (crc == RAMX_OK)
+      // from here on a multi-rank run never leaves before the second agreement (a rank that did would leave the others'
+      // kernels spinning to their limit and then waiting in a collective it never joins)
+      int lrc = RAMX_OK;
+      auto launch = [&]() -> int
       {
+        CPArgs ca;
+        memset(&ca, 0, sizeof(ca));
+        ca.bases = d->d_bases; ca.bounds = d->d_bounds; ca.trim = d->d_trim; ca.ctl_out = d->d_ctl; ca.cons_out = d->d_cons;
+        ca.Np = d->Np; ca.KW = d->KW; ca.L = L; ca.go = a.go; ca.ge = a.ge; ca.cap = a.cap; ca.minimp = a.minimp; ca.when_to_stop = a.when_to_stop;
+        memcpy(ca.tab, d->tab, sizeof(ca.tab));
+        ca.Nx = d->Nx; ca.nblocks = nb; ca.vote = d->d_vote; ca.err = d->d_err; ca.S = d->d_state[0];
+        ca.nranks = 1; ca.rank = 0;
+        if (multi)
+        {
+          ca.nranks = d->nranks; ca.rank = d->rank; ca.peers = (PeerBox *const *)d->d_peer; ca.box = d->xbox; ca.mirror = NULL;
+          if (d->hostbox_host)
+          {
+            if (!d->hostbox_mirror) HIPCHK(hipMalloc((void **)&d->hostbox_mirror, sizeof(PeerBox)));
+            HIPCHK(hipMemsetAsync(d->hostbox_mirror, 0, sizeof(PeerBox), d->stream));
+            ca.mirror = d->hostbox_mirror;
+          }
+          const char *tf = getenv("RAMX_TEST_FAIL_PRK_RANK");      // test hook: this rank fails where a launch error would
+          if (tf && atoi(tf) == d->rank) { ramx_set_error("test hook: forced failure of the cell-parallel launch on rank %d", d->rank); return RAMX_ERR_HIP; }
+        }
+        HIPCHK(hipMemsetAsync(d->d_vote, 0, 3 * NSHARD * sizeof(PShard), d->stream));
+        HIPCHK(hipMemsetAsync(d->d_err, 0, 64, d->stream));
+        HIPCHK(hipMemsetAsync(d->d_ctl, 0, 2 * sizeof(RamxCtl), d->stream));
+        HIPCHK(hipEventRecord(d->ev_begin, d->stream));
+        int crc = ramx_cp_launch_device(d->stream, a.W, k, th, nb, ca);
+        if (crc != RAMX_OK) { ramx_set_error("cell-parallel device launch failed (W %d, %d lanes per flank, %d workgroups)", a.W, k, nb); return crc; }
         HIPCHK(hipEventRecord(d->ev_end, d->stream));
         HIPCHK(hipStreamSynchronize(d->stream));
-        RamxCtl c0;
-        HIPCHK(hipMemcpy(&c0, d->d_ctl, sizeof(c0), hipMemcpyDeviceToHost));
-        if (c0.pad == 0) { persistent = true; lanes = k; launches = 1; }
-        else fprintf(stderr, "ramx: device-wide vote of the cell-parallel launch timed out (bounded spin); repeating the direction with "
-                             "per-column launches\n");
+        return RAMX_OK;
+      };
+      lrc = launch();
+      RamxCtl c0;
+      memset(&c0, 0, sizeof(c0));
+      int bad = lrc != RAMX_OK;
+      if (!bad && hipMemcpy(&c0, d->d_ctl, sizeof(c0), hipMemcpyDeviceToHost) != hipSuccess) bad = 1;
+      bad = bad || c0.pad != 0;
+      if (multi)
+      {
+        if (lrc != RAMX_OK) (void)hipStreamSynchronize(d->stream);
+        int frc = host_allreduce_flag(d, &bad);
+        if (frc != RAMX_OK) return frc;
+        if (bad)
+        {
+          fprintf(stderr, "ramx: cross-device cell-parallel launch gave up or failed on some rank; repeating the direction with per-column "
+                          "launches and leaving the mailbox path off for the rest of this process\n");
+          d->peer_ready = 0;        // agreed by all ranks (the flag above is reduced)
+        }
       }
-      else if (crc != RAMX_ERR_UNSUPPORTED) { ramx_set_error("cell-parallel device launch failed (W %d, %d lanes per flank, %d workgroups)", a.W, k, nb); return crc; }
+      else if (lrc != RAMX_OK) return lrc;
+      else if (bad)
+        fprintf(stderr, "ramx: device-wide vote of the cell-parallel launch timed out (bounded spin); repeating the direction with "
+                        "per-column launches\n");
+      if (!bad) { persistent = true; lanes = k; launches = 1; }
     }
   }
   const bool cp_done = persistent;

@@ -541,9 +541,65 @@ __global__ __launch_bounds__((CpCfg<W, K>::MAXT > 0 ? CpCfg<W, K>::MAXT : 64), C
       }
 #pragma unroll
       for (int mm = 16; mm >= 1; mm >>= 1) { y0 += __shfl_xor(y0, mm, 64); y1 += __shfl_xor(y1, mm, 64); }
-      if (lane == 0) { sm.vote[2][0] = (unsigned long long)y0; sm.vote[2][1] = (unsigned long long)y1; sm.fail = failed; }
-      if (lane == 32) { sm.vote[2][2] = (unsigned long long)y0; sm.vote[2][3] = (unsigned long long)y1; }
-      if (lane == 0 && failed) __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      long long v[4] = { __shfl(y0, 0, 64), __shfl(y1, 0, 64), __shfl(y0, 32, 64), __shfl(y1, 32, 64) };   // this GPU's totals
+      if (a.nranks > 1 && !failed)
+      {
+        // ---- cross-device step (flanks sharded over ranks).  Workgroup 0 of every rank stores its rank's four totals,
+        // tagged with the column number, into slot [r % 3][rank] of every OTHER rank's mailbox (system-scope stores over
+        // xGMI, or PCIe for the host-memory boxes); every workgroup adds the other ranks' words to the local totals it has
+        // just folded itself -- the local part never takes the detour through a mailbox.
+        const unsigned long long tag = (unsigned long long)(r & 0xffff) << 48;
+        const bool other = lane < a.nranks && lane != a.rank;
+        if (blockIdx.x == 0 && other)
+        {
+          PeerBox *pb = a.peers[lane];
+#pragma unroll
+          for (int k = 0; k < 4; k++)
+          {
+            if (v[k] >= PEER_VBIAS || v[k] <= -PEER_VBIAS) failed = 1;     // cannot be encoded: fail loudly
+            __hip_atomic_store(&pb->slot[r % 3][a.rank][k], tag | ((unsigned long long)(v[k] + PEER_VBIAS) & PEER_VMASK),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          }
+        }
+        unsigned long long yy[4] = { 0, 0, 0, 0 };
+        bool got = !other;
+        unsigned spins2 = 0;
+        const PeerBox *pollbox = (a.mirror != NULL && blockIdx.x != 0) ? a.mirror : a.box;
+        for (;;)
+        {
+          if (!got)
+          {
+#pragma unroll
+            for (int k = 0; k < 4; k++) yy[k] = __hip_atomic_load(&pollbox->slot[r % 3][lane][k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            got = (yy[0] >> 48) == (tag >> 48) && (yy[1] >> 48) == (tag >> 48) && (yy[2] >> 48) == (tag >> 48) && (yy[3] >> 48) == (tag >> 48);
+            if (got && a.mirror != NULL && blockIdx.x == 0)
+            {
+              // host-memory boxes: only workgroup 0 polls across PCIe; it passes every arriving word on to the local pollers
+#pragma unroll
+              for (int k = 0; k < 4; k++)
+                __hip_atomic_store(&a.mirror->slot[r % 3][lane][k], yy[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+          }
+          if (__all(got)) break;
+          if (++spins2 > PRK_SPIN_LIMIT || ((spins2 & 1023u) == 0 && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0))
+          {
+            failed = 1;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+        failed = __any(failed) ? 1 : 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+          v[k] += wave_sum_ll((other && !failed) ? (long long)(yy[k] & PEER_VMASK) - PEER_VBIAS : 0LL);
+      }
+      if (lane == 0)
+      {
+        sm.vote[2][0] = (unsigned long long)v[0]; sm.vote[2][1] = (unsigned long long)v[1];
+        sm.vote[2][2] = (unsigned long long)v[2]; sm.vote[2][3] = (unsigned long long)v[3];
+        sm.fail = failed;
+        if (failed) __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   };

@@ -21,7 +21,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out, peer=False, W=20, kind="", fail_rank=None):
+def _worker(rank, world, port, out, peer=False, W=20, kind="", fail_rank=None, no_cp=False):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -50,6 +50,8 @@ def _worker(rank, world, port, out, peer=False, W=20, kind="", fail_rank=None):
     p = po.Params.named("14p43g", bandwidth=W, L=150, when_to_stop=25)
     if fail_rank is not None:
         os.environ["RAMX_TEST_FAIL_PRK_RANK"] = str(fail_rank)
+    if no_cp:
+        os.environ["RAMX_NO_CP_DEVICE"] = "1"           # the lane-per-flank persistent kernel instead of the cell-parallel one
     dev = Device(0)
     dev.set_allreduce_callback(allreduce4)
     enabled = False
@@ -73,8 +75,9 @@ def _worker(rank, world, port, out, peer=False, W=20, kind="", fail_rank=None):
     for d in (1, 0):
         rets.append(extend_alignment_sharded(d, c, fs.sequence, m, to_extend_params(p), rank, world, gpu_engine(dev), all_gather))
     used_persistent = dev.last.persistent
+    lanes = dev.last.lanes_per_flank
     dev.close()
-    out[rank] = (rets, m.copy(), c.left_len.copy(), c.right_len.copy(), c.score.copy(), enabled, used_persistent)
+    out[rank] = (rets, m.copy(), c.left_len.copy(), c.right_len.copy(), c.score.copy(), enabled, used_persistent, lanes)
     dist.destroy_process_group()
 
 
@@ -90,33 +93,37 @@ def test_two_ranks_one_gpu_equal_single_process_oracle():
     c = fs.cores.copy(); m = new_master(p.L)
     r1 = po.oracle_extend(1, c, fs.sequence, m, p); r0 = po.oracle_extend(0, c, fs.sequence, m, p)
     for rank in range(world):
-        rets, mm, ll, rl, sc, enabled, used = out[rank]
+        rets, mm, ll, rl, sc, enabled, used, lanes = out[rank]
         assert rets == [(r1.ret, r1.rows_executed), (r0.ret, r0.rows_executed)], rank
         assert np.array_equal(mm, m) and np.array_equal(ll, c.left_len) and np.array_equal(rl, c.right_len)
         assert np.array_equal(sc, c.score)
         assert used == 0
 
 
+@pytest.mark.parametrize("no_cp", [False, True], ids=["cell-parallel", "lane-per-flank"])
 @pytest.mark.parametrize("W,kind", [(14, "device"), (40, "device"), (20, "host"), (40, "host"), (40, "")])
-def test_two_ranks_cross_device_persistent_path(W, kind):
+def test_two_ranks_cross_device_persistent_path(W, kind, no_cp):
     """Same two ranks, but with the mailboxes enabled: each rank runs ONE persistent launch per direction and the
     per-column vote is exchanged from inside the kernels (system-scope stores into every rank's box).  kind "device":
     fine-grained device memory mapped over hipIpc; "host": one POSIX shared-memory segment registered with HIP; "":
-    the production order (device first).  The two cooperative launches share the test box's single GPU."""
+    the production order (device first).  Both kernels that carry the exchange: the cell-parallel kernel (K lanes per
+    flank, speculation on the workgroup's vote) and the lane-per-flank persistent kernel.  The two launches share the
+    test box's single GPU."""
     from oracle import pyoracle as po
     from repeatafterme_amd.datamodel import new_master
     from repeatafterme_amd.synth import synth_family
     world = 2
     out = mp.Manager().dict()
-    mp.spawn(_worker, args=(world, _free_port(), out, True, W, kind), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), out, True, W, kind, None, no_cp), nprocs=world, join=True)
     fs = synth_family(333, 150, W, K=100, seed=12, both_sides=True, minus_frac=0.3, n_run_frac=0.1)
     p = po.Params.named("14p43g", bandwidth=W, L=150, when_to_stop=25)
     c = fs.cores.copy(); m = new_master(p.L)
     r1 = po.oracle_extend(1, c, fs.sequence, m, p); r0 = po.oracle_extend(0, c, fs.sequence, m, p)
     for rank in range(world):
-        rets, mm, ll, rl, sc, enabled, used = out[rank]
+        rets, mm, ll, rl, sc, enabled, used, lanes = out[rank]
         assert enabled, "peer self-test failed"
         assert used == 1, "cross-device persistent launch was not taken (or fell back)"
+        assert (lanes == 1) == no_cp, lanes
         assert rets == [(r1.ret, r1.rows_executed), (r0.ret, r0.rows_executed)], rank
         assert np.array_equal(mm, m) and np.array_equal(ll, c.left_len) and np.array_equal(rl, c.right_len)
         assert np.array_equal(sc, c.score)
@@ -137,7 +144,7 @@ def test_rank_local_failure_after_agreement_falls_back_on_all_ranks():
     c = fs.cores.copy(); m = new_master(p.L)
     r1 = po.oracle_extend(1, c, fs.sequence, m, p); r0 = po.oracle_extend(0, c, fs.sequence, m, p)
     for rank in range(world):
-        rets, mm, ll, rl, sc, enabled, used = out[rank]
+        rets, mm, ll, rl, sc, enabled, used, lanes = out[rank]
         assert enabled
         assert used == 0, "the direction must have been repeated with per-column launches on every rank"
         assert rets == [(r1.ret, r1.rows_executed), (r0.ret, r0.rows_executed)], rank
