@@ -34,6 +34,18 @@ int ramx_cp_max_family(int W, int go, int ge, const int (&tab)[RAMX_NCLASS][4], 
   return best;
 }
 
+// Largest single family for which ONE workgroup is the faster place (blocks of up to 21 cells per lane): above it the
+// device-wide mode with 16 lanes per flank wins (W = 40, 250 flanks: 4.1 us per column in one workgroup at K = 2, 2.6
+// device-wide; profiles/r02_cp_family_timing.log).  Batches keep every family that fits in one workgroup: there a family
+// per CU is the better use of the chip.
+int ramx_cp_single_family_max(int W)
+{
+  int best = 0;
+  for (int K = 16; K >= 2; K >>= 1)
+    if (cp_cells(W, K) <= 21 && cp_max_threads(W, cp_cells(W, K)) / K > best) best = cp_max_threads(W, cp_cells(W, K)) / K;
+  return best;
+}
+
 // A family takes the most lanes per flank (16, 8, 4, 2) that keep it within one 512-thread workgroup; the classes are
 // (lanes per flank, workgroup size): families of up to 16 flanks run 16 lanes per flank in 256 threads.
 int ramx_cp_class(int W, int nx, int *K, int *threads)

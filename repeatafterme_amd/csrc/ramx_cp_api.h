@@ -6,6 +6,17 @@
 
 #include "ramx_kernels_common.h"
 
+// device-wide mode: one entry per workgroup.  A launch may hold several flank sets ("families" too large for one
+// workgroup): the workgroups of one set vote among themselves through their own ticket words / error word / outputs.
+struct CpDevDesc
+{
+  int first;        // first flank of the set in the flank arrays
+  int nx;           // flanks of the set
+  int b, nb;        // this workgroup's index inside the set, workgroups of the set
+  int id;           // set index: vote words at vote + id * 3 * NSHARD, err + id * 16, ctl_out[id], cons_out + id * L
+  int pad[3];
+};
+
 struct CPArgs
 {
   const unsigned *bases;        // [KW][Np] packed windows (ramx_pack_kernel)
@@ -19,7 +30,7 @@ struct CPArgs
   int tab[RAMX_NCLASS][4];
   unsigned long long *dbg;      // -DRAMX_CP_TIMING builds only: [wave of block 0][8] phase sums in shader clocks
   // device-wide mode (one flank set over the whole grid)
-  int Nx, nblocks;              // flanks that exist (the rest of [0, Np) is padding); workgroups of the launch
+  const CpDevDesc *dev;         // [workgroups of the launch]
   struct PShard *vote;          // [3][NSHARD] ticketed vote words (zeroed by the host before the launch)
   unsigned *err;                // != 0: a bounded spin gave up
   int4 *S;                      // optional: final rows in the lane-per-flank layout (ramx_dev_peek_state), else NULL
@@ -36,6 +47,7 @@ struct CPArgs
 int ramx_cp_max_family(int W, int go, int ge, const int (&tab)[RAMX_NCLASS][4], int L);
 // class of a family of nx flanks (0 .. RAMX_CP_NCLASS-1): lanes per flank and workgroup size; -1 if too large
 int ramx_cp_class(int W, int nx, int *lanes_per_flank, int *threads);
+int ramx_cp_single_family_max(int W);
 int ramx_cp_launch_families(hipStream_t st, int W, int lanes_per_flank, int threads, int n_families, const CPArgs &a);
 // Device-wide mode: lanes per flank and workgroup count for n flanks on `cus` compute units (one 512-thread workgroup per
 // CU at most), 0 lanes if the set does not fit or the width / scoring system is not supported (ramx_cp_max_family > 0).

@@ -117,6 +117,8 @@ struct ramx_dev
   int force_chain;   // RAMX_FORCE_CHAIN=1: always run the full candidate recurrence (test hook)
   ramx_row_trace_cb trace_cb; void *trace_user;   // -outmat: per-row trace (forces the per-column launches)
   signed char *d_dbg_codes; int2 *d_dbg_best; size_t cap_dbg_codes, cap_dbg_best;
+  CpDevDesc *d_devdesc; size_t cap_devdesc;       // device-wide cell-parallel launches: one descriptor per workgroup
+  PShard *d_vote_sets; size_t cap_vote_sets; unsigned *d_err_sets; size_t cap_err_sets;   // batch mode: per-set vote / error words
   int cp_flanks_ok;    // begin_direction: every flank is empty or has t_lo <= 0 (what the cell-parallel kernels take)
   int2 *d_cpstate; size_t cap_cpstate; int cpstate_W, cpstate_n;   // RAMX_CP_PEEK=1: final rows of the cell-parallel kernel (tests)
 };
@@ -189,7 +191,7 @@ extern "C" void ramx_dev_destroy(ramx_dev *d)
     (void)hipEventDestroy(d->cls_ready);
   }
   if (d->devbox) (void)hipFree(d->devbox);
-  (void)hipFree(d->d_fam); (void)hipFree(d->d_famctl); (void)hipFree(d->d_cpstate); (void)hipFree(d->d_dbg_codes); (void)hipFree(d->d_dbg_best);
+  (void)hipFree(d->d_fam); (void)hipFree(d->d_famctl); (void)hipFree(d->d_cpstate); (void)hipFree(d->d_dbg_codes); (void)hipFree(d->d_dbg_best); (void)hipFree(d->d_devdesc); (void)hipFree(d->d_vote_sets); (void)hipFree(d->d_err_sets);
   if (d->hostbox_mirror) (void)hipFree(d->hostbox_mirror);
   if (d->d_peer) (void)hipFree(d->d_peer);
   for (int i = 0; i < 2; i++) if (d->ev_chk[i]) (void)hipEventDestroy(d->ev_chk[i]);
@@ -723,11 +725,20 @@ extern "C" int ramx_dev_run_families(ramx_dev *d, const ramx_flank *flanks, int3
   memset(cls_count, 0, sizeof(cls_count));
   memset(cp_k, 0, sizeof(cp_k)); memset(cp_threads, 0, sizeof(cp_threads));
   auto cls_of = [](int nx) { return nx <= 64 ? 0 : nx <= 128 ? 1 : nx <= 256 ? 2 : 3; };
-  int n_cp = 0;
+  // Families above one cell-parallel workgroup (group -1): several workgroups per family, the family's vote through its
+  // own ticket words -- the device-wide mode of the same kernel, all such families in ONE launch of at most one
+  // workgroup per CU (every workgroup must be resident).
+  int n_cp = 0, n_dev = 0, dev_blocks = 0, dev_k = 0, dev_threads = 0, cus = 0;
+  std::vector<CpDevDesc> hdev;
+  {
+    int devo = 0;
+    if (hipGetDevice(&devo) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, devo) != hipSuccess) cus = 0;
+  }
+  const bool dev_route = cp_max > 0 && cus > 0 && getenv("RAMX_NO_CP_DEVICE") == NULL && getenv("RAMX_NO_PERSISTENT") == NULL;
   for (int f = 0; f < n_families; f++)
   {
     int g = RAMX_CP_NCLASS + cls_of(fam_count[f]);
-    if (fam_count[f] > 0 && fam_count[f] <= cp_max)
+    if (fam_count[f] > 0 && cp_max > 0)
     {
       bool ok = true;
       for (int i = 0; i < fam_count[f] && ok; i++)
@@ -736,11 +747,30 @@ extern "C" int ramx_dev_run_families(ramx_dev *d, const ramx_flank *flanks, int3
         ok = (x.t_lo <= 0) || (x.t_lo > x.t_hi);
       }
       int k = 0, th = 0;
-      const int c = ok ? ramx_cp_class(W, fam_count[f], &k, &th) : -1;
+      const int c = (ok && fam_count[f] <= cp_max) ? ramx_cp_class(W, fam_count[f], &k, &th) : -1;
       if (c >= 0) { g = c; cp_k[c] = k; cp_threads[c] = th; n_cp++; }
+      else if (ok && dev_route)
+      {
+        int nb = 0;
+        ramx_cp_device_plan(W, fam_count[f], cus, &k, &th, &nb);
+        if (k > 0 && (dev_k == 0 || (k == dev_k && th == dev_threads)) && dev_blocks + nb <= cus)
+        {
+          dev_k = k; dev_threads = th;
+          for (int b = 0; b < nb; b++)
+          {
+            CpDevDesc x;
+            memset(&x, 0, sizeof(x));
+            x.first = fam_first[f]; x.nx = fam_count[f]; x.b = b; x.nb = nb; x.id = f;
+            hdev.push_back(x);
+          }
+          dev_blocks += nb;
+          n_dev++;
+          g = -1;
+        }
+      }
     }
     grp[f] = g;
-    cls_count[g]++;
+    if (g >= 0) cls_count[g]++;
   }
   cls_first[0] = 0;
   for (int c = 0; c < RAMX_NGROUP; c++) cls_first[c + 1] = cls_first[c] + cls_count[c];
@@ -749,6 +779,7 @@ extern "C" int ramx_dev_run_families(ramx_dev *d, const ramx_flank *flanks, int3
     for (int c = 0; c < RAMX_NGROUP; c++) fill[c] = cls_first[c];
     for (int f = 0; f < n_families; f++)
     {
+      if (grp[f] < 0) continue;
       FamDesc &x = hfd[fill[grp[f]]++];
       x.tile0 = fam_first[f] / 64; x.ntiles = (fam_count[f] + 63) / 64; x.nx = fam_count[f]; x.id = f;
     }
@@ -762,7 +793,7 @@ extern "C" int ramx_dev_run_families(ramx_dev *d, const ramx_flank *flanks, int3
     ramx_set_error("HIP error %s at %s:%d (%s)", hipGetErrorString(e_), __FILE__, __LINE__, #call); rc = RAMX_ERR_HIP; goto done; } } while (0)
   FamDesc *dfd; RamxCtl *dctl;
   FArgs fa;
-  const bool legacy_any = n_cp < n_families;
+  const bool legacy_any = n_cp + n_dev < n_families;
   if ((rc = ensure(&d->d_fam, &d->cap_fam, sizeof(FamDesc) * (size_t)n_families))) goto done;
   if ((rc = ensure(&d->d_famctl, &d->cap_famctl, sizeof(RamxCtl) * (size_t)n_families))) goto done;
   dfd = (FamDesc *)d->d_fam; dctl = d->d_famctl;
@@ -799,6 +830,29 @@ extern "C" int ramx_dev_run_families(ramx_dev *d, const ramx_flank *flanks, int3
   // every group stream waits (the register-resident branch below merges shapes AFTER this point: a stream that is
   // launched on must never have skipped the wait -- uploads and the pack kernel run on the library's stream)
   for (int c = 0; c < RAMX_NGROUP; c++) FAMCHK(hipStreamWaitEvent(d->cls_stream[c], d->cls_ready, 0));
+  // ---- families above one workgroup: device-wide mode, one launch, enqueued first ----------------
+  if (n_dev > 0)
+  {
+    CPArgs ca;
+    memset(&ca, 0, sizeof(ca));
+    ca.bases = d->d_bases; ca.bounds = d->d_bounds; ca.trim = d->d_trim; ca.ctl_out = dctl; ca.cons_out = d->d_cons;
+    ca.Np = Np; ca.KW = KW; ca.L = L; ca.go = p->gapopen; ca.ge = p->gapextn; ca.cap = p->cappenalty; ca.minimp = p->minimprovement;
+    ca.when_to_stop = p->when_to_stop;
+    memcpy(ca.tab, tab9, sizeof(ca.tab));
+    ca.nranks = 1; ca.rank = 0;
+    if ((rc = ensure(&d->d_devdesc, &d->cap_devdesc, sizeof(CpDevDesc) * hdev.size()))) goto done;
+    if ((rc = ensure(&d->d_vote_sets, &d->cap_vote_sets, sizeof(PShard) * 3 * NSHARD * (size_t)n_families))) goto done;
+    if ((rc = ensure(&d->d_err_sets, &d->cap_err_sets, 64 * (size_t)n_families))) goto done;
+    {
+      hipStream_t st = d->cls_stream[RAMX_NGROUP - 1];       // shares a stream with the last lane-per-flank shape, enqueued before it
+      FAMCHK(hipMemcpyAsync(d->d_devdesc, hdev.data(), sizeof(CpDevDesc) * hdev.size(), hipMemcpyHostToDevice, st));
+      FAMCHK(hipMemsetAsync(d->d_vote_sets, 0, sizeof(PShard) * 3 * NSHARD * (size_t)n_families, st));
+      FAMCHK(hipMemsetAsync(d->d_err_sets, 0, 64 * (size_t)n_families, st));
+      ca.dev = d->d_devdesc; ca.vote = d->d_vote_sets; ca.err = d->d_err_sets;
+      rc = ramx_cp_launch_device(st, W, dev_k, dev_threads, dev_blocks, ca);
+      if (rc != RAMX_OK) { ramx_set_error("cell-parallel multi-family device launch failed (W %d, %d workgroups)", W, dev_blocks); goto done; }
+    }
+  }
   // ---- cell-parallel groups ------------------------------------------------------------------
   if (n_cp > 0)
   {
@@ -886,7 +940,8 @@ extern "C" int ramx_dev_run_families(ramx_dev *d, const ramx_flank *flanks, int3
     }
   }
   for (int c = 0; c < RAMX_NGROUP; c++)
-    if (cls_count[c] > 0) { FAMCHK(hipEventRecord(d->cls_done[c], d->cls_stream[c])); FAMCHK(hipStreamWaitEvent(d->stream, d->cls_done[c], 0)); }
+    if (cls_count[c] > 0 || (c == RAMX_NGROUP - 1 && n_dev > 0))
+    { FAMCHK(hipEventRecord(d->cls_done[c], d->cls_stream[c])); FAMCHK(hipStreamWaitEvent(d->stream, d->cls_done[c], 0)); }
   FAMCHK(hipEventRecord(d->ev_end, d->stream));
   FAMCHK(hipStreamSynchronize(d->stream));
   FAMCHK(hipEventElapsedTime(&ms, d->ev_begin, d->ev_end));
@@ -929,8 +984,9 @@ extern "C" int ramx_dev_run_families(ramx_dev *d, const ramx_flank *flanks, int3
     FAMCHK(hipMemcpy(tmp, d->d_trim, (size_t)n_padded * sizeof(int2), hipMemcpyDeviceToHost));
     for (int i = 0; i < n_padded; i++) { if (trim_high) trim_high[i] = tmp[i].x; if (trim_pos) trim_pos[i] = tmp[i].y; }
   }
-  for (int f = 0; f < n_families && infos; f++)
+  for (int f = 0; f < n_families; f++)
   {
+    if (!infos) { if (grp[f] < 0 && hctl[f].pad != 0) { ramx_set_error("batch mode: the vote of a multi-workgroup family timed out"); rc = RAMX_ERR_STATE; goto done; } continue; }
     memset(&infos[f], 0, sizeof(ramx_run_info));
     infos[f].ret = hctl[f].max_row + 1;
     infos[f].rows_executed = hctl[f].rows_done;
@@ -941,7 +997,13 @@ extern "C" int ramx_dev_run_families(ramx_dev *d, const ramx_flank *flanks, int3
     infos[f].loop_ms = ms;
     /* 1: rows resident in registers (3: of K lanes per flank, the cell-parallel kernel); 2: streaming family kernel */
     infos[f].persistent = grp[f] < RAMX_CP_NCLASS ? 1 : (resident ? 1 : 2);
-    infos[f].lanes_per_flank = grp[f] < RAMX_CP_NCLASS ? cp_k[grp[f]] : 1;
+    infos[f].lanes_per_flank = grp[f] < 0 ? dev_k : (grp[f] < RAMX_CP_NCLASS ? cp_k[grp[f]] : 1);
+    if (grp[f] < 0 && hctl[f].pad != 0)
+    {
+      ramx_set_error("batch mode: the vote of a multi-workgroup family timed out (bounded spin gave up)");
+      rc = RAMX_ERR_STATE;
+      goto done;
+    }
   }
   rc = RAMX_OK;
 done:
@@ -1011,7 +1073,15 @@ extern "C" int ramx_dev_run_direction(ramx_dev *d, ramx_run_info *info)
         ca.bases = d->d_bases; ca.bounds = d->d_bounds; ca.trim = d->d_trim; ca.ctl_out = d->d_ctl; ca.cons_out = d->d_cons;
         ca.Np = d->Np; ca.KW = d->KW; ca.L = L; ca.go = a.go; ca.ge = a.ge; ca.cap = a.cap; ca.minimp = a.minimp; ca.when_to_stop = a.when_to_stop;
         memcpy(ca.tab, d->tab, sizeof(ca.tab));
-        ca.Nx = d->Nx; ca.nblocks = nb; ca.vote = d->d_vote; ca.err = d->d_err; ca.S = d->d_state[0];
+        {
+          std::vector<CpDevDesc> hd((size_t)nb);
+          for (int i = 0; i < nb; i++) { memset(&hd[i], 0, sizeof(CpDevDesc)); hd[i].first = 0; hd[i].nx = d->Nx; hd[i].b = i; hd[i].nb = nb; hd[i].id = 0; }
+          int drc = ensure(&d->d_devdesc, &d->cap_devdesc, sizeof(CpDevDesc) * (size_t)nb);
+          if (drc != RAMX_OK) return drc;
+          HIPCHK(hipMemcpyAsync(d->d_devdesc, hd.data(), sizeof(CpDevDesc) * (size_t)nb, hipMemcpyHostToDevice, d->stream));
+          HIPCHK(hipStreamSynchronize(d->stream));       // hd goes out of scope
+        }
+        ca.dev = d->d_devdesc; ca.vote = d->d_vote; ca.err = d->d_err; ca.S = d->d_state[0];
         ca.nranks = 1; ca.rank = 0;
         if (multi)
         {
@@ -1288,6 +1358,25 @@ extern "C" int ramx_dev_peek_family_state(ramx_dev *d, int32_t flank, int32_t *c
   const int B = 2 * d->cpstate_W + 1;
   HIPCHK(hipMemcpy(cells, d->d_cpstate + (size_t)flank * B, (size_t)B * sizeof(int2), hipMemcpyDeviceToHost));
   return RAMX_OK;
+}
+
+// Largest family (extendable cores in one direction) that seam 1 should hand to the one-workgroup-per-family route; larger
+// sets go through ramx_dev_run_direction, whose device-wide cell-parallel kernel beats the lane-per-flank family kernel
+// (W = 40, 500 flanks: 2.6 vs 7.3 us per column).  512 where the cell-parallel kernel does not apply.
+extern "C" int ramx_dev_family_route_max(ramx_dev *d, const ramx_params *p)
+{
+  if (!d || !p || !p->matrix) return 512;
+  int tab9[RAMX_NCLASS][4];
+  for (int c = 0; c < RAMX_NCLASS; c++)
+  {
+    const int code = (c == 8) ? RAMX_SYM_N : c;
+    for (int k = 0; k < 4; k++) tab9[c][k] = p->matrix[k * 100 + code];
+  }
+  if (d->force_chain || getenv("RAMX_NO_CP_DEVICE") != NULL || getenv("RAMX_NO_PERSISTENT") != NULL) return 512;
+  const int m = ramx_cp_max_family(p->bandwidth, p->gapopen, p->gapextn, tab9, p->L);
+  if (m <= 0) return 512;
+  const int s1 = ramx_cp_single_family_max(p->bandwidth);
+  return s1 < m ? s1 : m;
 }
 
 extern "C" int ramx_dev_set_row_trace(ramx_dev *d, ramx_row_trace_cb cb, void *user)

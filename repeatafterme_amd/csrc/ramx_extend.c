@@ -232,7 +232,7 @@ int ramx_extend_flat(int direction, ramx_flat_cores *c, const int8_t *sequence, 
     tctx.cores = c; tctx.sequence = sequence;
     ramx_dev_set_row_trace(d, trace_row, &tctx);
   }
-  if (g_trace_file == NULL && nx > 0 && nx <= 512 && L > 0 && W >= 1 && getenv("RAMX_NO_FAMILY_ROUTE") == NULL)
+  if (g_trace_file == NULL && nx > 0 && nx <= ramx_dev_family_route_max(d, p) && L > 0 && W >= 1 && getenv("RAMX_NO_FAMILY_ROUTE") == NULL)
   {
     /* a family that fits one workgroup needs no device-wide barrier: run it as a batch of one (block-local vote) */
     const int npad = (nx + 63) & ~63;

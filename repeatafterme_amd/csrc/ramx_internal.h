@@ -17,6 +17,9 @@ int ramx_runtime_verbose(void);
 int ramx_runtime_when_to_stop(void);
 int ramx_runtime_l(void);
 
+/* seam 1's routing: families up to this many extendable cores run as a batch of one (csrc/ramx_device.hip) */
+int ramx_dev_family_route_max(ramx_dev *d, const ramx_params *p);
+
 /* process-wide device session used by seam 1 (created on first use) */
 ramx_dev *ramx_default_device(void);
 

@@ -343,20 +343,26 @@ __global__ __launch_bounds__((CpCfg<W, K>::MAXT > 0 ? CpCfg<W, K>::MAXT : 64), C
   // every column ends with one predicated copy per state register (phi of old and new row)
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   FamDesc fd;
+  CpDevDesc dd;
+  dd.first = 0; dd.nx = 0; dd.b = 0; dd.nb = 1; dd.id = 0;
   if (DEV)
   {
-    // the grid covers flanks [0, Np): workgroup b holds blockDim / K consecutive flanks
+    // workgroup b of a set holds blockDim / K consecutive flanks of it
+    dd = a.dev[blockIdx.x];
     const int per = blockDim.x / K;
-    fd.tile0 = 0; fd.ntiles = 0; fd.id = 0;
-    fd.nx = a.Nx - blockIdx.x * per;                 // flanks (of this workgroup) that exist
+    fd.tile0 = 0; fd.ntiles = 0; fd.id = dd.id;
+    fd.nx = dd.nx - dd.b * per;                      // flanks (of this workgroup) that exist
     fd.nx = fd.nx < 0 ? 0 : (fd.nx > per ? per : fd.nx);
   }
   else fd = a.fam[blockIdx.x];
+  const int wg = DEV ? dd.b : 0;                     // index of this workgroup inside its flank set
+  PShard *const vote = a.vote + (size_t)dd.id * 3 * NSHARD;      // DEV only
+  unsigned *const errw = a.err + (size_t)dd.id * 16;
   const int f = threadIdx.x / K;                     // flank inside the family / workgroup
   const bool live = wave * FPW < fd.nx;              // wave-uniform: does this wave hold any flank?
   const bool active = f < fd.nx;
-  const int n = DEV ? blockIdx.x * (blockDim.x / K) + (live ? f : 0) : fd.tile0 * 64 + (live ? f : 0);
-  const int my_shard_blocks = DEV ? (a.nblocks - (lane & (NSHARD - 1)) + NSHARD - 1) / NSHARD : 0;   // wave 0: blocks arriving on shard lane & 31
+  const int n = DEV ? dd.first + wg * (blockDim.x / K) + (live ? f : 0) : fd.tile0 * 64 + (live ? f : 0);
+  const int my_shard_blocks = DEV ? (dd.nb - (lane & (NSHARD - 1)) + NSHARD - 1) / NSHARD : 0;   // wave 0: blocks arriving on shard lane & 31
   int failed = 0;
 
   if (threadIdx.x < 16)
@@ -492,12 +498,12 @@ __global__ __launch_bounds__((CpCfg<W, K>::MAXT > 0 ? CpCfg<W, K>::MAXT : 64), C
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (DEV)
     {
-      if (blockIdx.x == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // workgroup 0: its clearing stores first
+      if (wg == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // workgroup 0: its clearing stores first
       if (threadIdx.x < 4)
       {
         const unsigned long long t = sm.vote[(r + 1) & 1][threadIdx.x];
         sm.vote[r & 1][threadIdx.x] = 0ULL;          // the OTHER buffer: read by everybody a column ago, added to again after the next barrier
-        PShard *sh = a.vote + (size_t)((r + 4) % 3) * NSHARD + (blockIdx.x % NSHARD);
+        PShard *sh = vote + (size_t)((r + 4) % 3) * NSHARD + (wg % NSHARD);
         __hip_atomic_fetch_add(&sh->word[threadIdx.x], t + PRK_BIAS + PRK_TICKET, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
@@ -510,7 +516,7 @@ __global__ __launch_bounds__((CpCfg<W, K>::MAXT > 0 ? CpCfg<W, K>::MAXT : 64), C
     if (wave == 0)
     {
       const int sidx = lane & (NSHARD - 1), half = lane >> 5;
-      const unsigned long long *src = &a.vote[(size_t)(r % 3) * NSHARD + sidx].word[2 * half];
+      const unsigned long long *src = &vote[(size_t)(r % 3) * NSHARD + sidx].word[2 * half];
       unsigned spins = 0;
       bool done = my_shard_blocks <= 0;
       unsigned long long x0 = 0, x1 = 0;
@@ -526,7 +532,7 @@ __global__ __launch_bounds__((CpCfg<W, K>::MAXT > 0 ? CpCfg<W, K>::MAXT : 64), C
           done = (x0 >> 54) >= (unsigned long long)my_shard_blocks && (x1 >> 54) >= (unsigned long long)my_shard_blocks;
         }
         if (__all(done)) break;
-        if (++spins > PRK_SPIN_LIMIT || ((spins & 1023u) == 0 && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0))
+        if (++spins > PRK_SPIN_LIMIT || ((spins & 1023u) == 0 && __hip_atomic_load(errw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0))
         {
           failed = 1;
           break;
@@ -550,7 +556,7 @@ __global__ __launch_bounds__((CpCfg<W, K>::MAXT > 0 ? CpCfg<W, K>::MAXT : 64), C
         // just folded itself -- the local part never takes the detour through a mailbox.
         const unsigned long long tag = (unsigned long long)(r & 0xffff) << 48;
         const bool other = lane < a.nranks && lane != a.rank;
-        if (blockIdx.x == 0 && other)
+        if (wg == 0 && other)
         {
           PeerBox *pb = a.peers[lane];
 #pragma unroll
@@ -564,7 +570,7 @@ __global__ __launch_bounds__((CpCfg<W, K>::MAXT > 0 ? CpCfg<W, K>::MAXT : 64), C
         unsigned long long yy[4] = { 0, 0, 0, 0 };
         bool got = !other;
         unsigned spins2 = 0;
-        const PeerBox *pollbox = (a.mirror != NULL && blockIdx.x != 0) ? a.mirror : a.box;
+        const PeerBox *pollbox = (a.mirror != NULL && wg != 0) ? a.mirror : a.box;
         for (;;)
         {
           if (!got)
@@ -572,7 +578,7 @@ __global__ __launch_bounds__((CpCfg<W, K>::MAXT > 0 ? CpCfg<W, K>::MAXT : 64), C
 #pragma unroll
             for (int k = 0; k < 4; k++) yy[k] = __hip_atomic_load(&pollbox->slot[r % 3][lane][k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             got = (yy[0] >> 48) == (tag >> 48) && (yy[1] >> 48) == (tag >> 48) && (yy[2] >> 48) == (tag >> 48) && (yy[3] >> 48) == (tag >> 48);
-            if (got && a.mirror != NULL && blockIdx.x == 0)
+            if (got && a.mirror != NULL && wg == 0)
             {
               // host-memory boxes: only workgroup 0 polls across PCIe; it passes every arriving word on to the local pollers
 #pragma unroll
@@ -581,7 +587,7 @@ __global__ __launch_bounds__((CpCfg<W, K>::MAXT > 0 ? CpCfg<W, K>::MAXT : 64), C
             }
           }
           if (__all(got)) break;
-          if (++spins2 > PRK_SPIN_LIMIT || ((spins2 & 1023u) == 0 && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0))
+          if (++spins2 > PRK_SPIN_LIMIT || ((spins2 & 1023u) == 0 && __hip_atomic_load(errw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0))
           {
             failed = 1;
             break;
@@ -598,7 +604,7 @@ __global__ __launch_bounds__((CpCfg<W, K>::MAXT > 0 ? CpCfg<W, K>::MAXT : 64), C
         sm.vote[2][0] = (unsigned long long)v[0]; sm.vote[2][1] = (unsigned long long)v[1];
         sm.vote[2][2] = (unsigned long long)v[2]; sm.vote[2][3] = (unsigned long long)v[3];
         sm.fail = failed;
-        if (failed) __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (failed) __hip_atomic_store(errw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -711,12 +717,12 @@ __global__ __launch_bounds__((CpCfg<W, K>::MAXT > 0 ? CpCfg<W, K>::MAXT : 64), C
       if (threadIdx.x == 0) a.cons_out[(size_t)fd.id * a.L + r] = (signed char)besta;
       if (threadIdx.x < 4) sm.vote[(r + 2) % 3][threadIdx.x] = 0ULL;
     }
-    else if (blockIdx.x == 0)
+    else if (wg == 0)
     {
-      if (threadIdx.x == 0) a.cons_out[r] = (signed char)besta;
+      if (threadIdx.x == 0) a.cons_out[(size_t)dd.id * a.L + r] = (signed char)besta;
       if (threadIdx.x < NSHARD)     // workgroup 0 clears the device set of row r+2 (protocol: ramx_kernels_resident.h)
       {
-        PShard *z = a.vote + (size_t)((r + 2) % 3) * NSHARD + threadIdx.x;
+        PShard *z = vote + (size_t)((r + 2) % 3) * NSHARD + threadIdx.x;
 #pragma unroll
         for (int k = 0; k < 4; k++) __hip_atomic_store(&z->word[k], 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
@@ -808,10 +814,10 @@ __global__ __launch_bounds__((CpCfg<W, K>::MAXT > 0 ? CpCfg<W, K>::MAXT : 64), C
     if (ln.pL0) { int *p = S + (size_t)W * 64 * 4 + 2; p[0] = high; p[1] = pos; }
   }
   if (live && ln.pL0 && (!DEV || n < a.Np)) a.trim[n] = make_int2(thigh, tpos);
-  if (threadIdx.x == 0 && (!DEV || blockIdx.x == 0))
+  if (threadIdx.x == 0 && (!DEV || wg == 0))
   {
     RamxCtl o;
     o.max_ext = max_ext; o.max_row = max_row; o.stopped = stopped; o.rows_done = rows_done; o.overflow = ovf; o.besta = 0; o.pad = failed;
-    a.ctl_out[DEV ? 0 : fd.id] = o;
+    a.ctl_out[fd.id] = o;
   }
 }

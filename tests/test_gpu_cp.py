@@ -102,7 +102,7 @@ def test_cp_stop_rule_and_degenerate_inputs():
         assert a[2].rows_executed == b[2].rows_executed and b[2].lanes_per_flank == 16
 
 
-@pytest.mark.parametrize("W,n,K", [(14, 30, 16), (20, 60, 8), (20, 100, 4), (40, 200, 2), (80, 30, 16), (80, 60, 8), (80, 100, 4), (40, 30, 16), (40, 128, 4)])
+@pytest.mark.parametrize("W,n,K", [(14, 30, 16), (20, 60, 8), (20, 100, 4), (14, 200, 2), (80, 30, 16), (80, 60, 8), (40, 30, 16), (40, 128, 4)])
 def test_cp_state_bit_exact_per_cell(W, n, K, monkeypatch):
     """After L columns the DP row kept by the cell-parallel kernel equals the oracle's row, cell by cell, both states
     (what bnw_extend.c:1617-1648 asserts for the reference): the scan re-associates the insertion chain exactly."""
@@ -210,3 +210,17 @@ def test_cp_device_wide_config2_full():
     assert (a.ret, a.rows_executed) == (b.ret, b.rows_executed) == (1500, 1600)
     assert np.array_equal(m1, m2) and np.array_equal(c1.right_len, c2.right_len) and np.array_equal(c1.score, c2.score)
     assert b.lanes_per_flank == 16 and b.persistent == 1
+
+
+@pytest.mark.parametrize("W,matrix", [(80, "20p43g"), (40, "14p43g"), (14, "18p43g")])
+def test_cp_batch_with_families_above_one_workgroup(W, matrix):
+    """Families too large for one cell-parallel workgroup (W = 80: 129..512 flanks; W = 40: 257..512) run several
+    workgroups each, all of them in ONE device-wide launch next to the one-workgroup families of the same batch; each
+    family votes through its own ticket words.  Every family against its own oracle run."""
+    L = 140
+    sizes = (300, 40, 512, 129, 200, 90, 257, 140, 16, 400)
+    fams = [synth_family(n, L, W, K=60 + 11 * i, seed=1200 + i, both_sides=True, minus_frac=0.3, n_run_frac=0.1,
+                         core_len=(2 * W + 3 if i % 2 else 12)) for i, n in enumerate(sizes)]
+    p = po.Params.named(matrix, bandwidth=W, L=L, when_to_stop=30)
+    lanes = _check_batch(fams, p, min_cp=2 * len(sizes))
+    assert all(x > 1 for x in lanes), lanes
