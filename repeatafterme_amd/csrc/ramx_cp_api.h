@@ -8,12 +8,16 @@
 
 // device-wide mode: one entry per workgroup.  A launch may hold several flank sets ("families" too large for one
 // workgroup): the workgroups of one set vote among themselves through their own ticket words / error word / outputs.
+// device-wide mode: rotating sets of vote shards (row r uses set r % 4; workgroup 0 clears the set of row r+3 during column r,
+// a whole column before anybody adds to it -- see publish / wait_vote in ramx_kernels_cp.h)
+#define RAMX_CP_NSETS 4
+
 struct CpDevDesc
 {
   int first;        // first flank of the set in the flank arrays
   int nx;           // flanks of the set
   int b, nb;        // this workgroup's index inside the set, workgroups of the set
-  int id;           // set index: vote words at vote + id * 3 * NSHARD, err + id * 16, ctl_out[id], cons_out + id * L
+  int id;           // set index: vote words at vote + id * RAMX_CP_NSETS * NSHARD, err + id * 16, ctl_out[id], cons_out + id * L
   int pad[3];
 };
 

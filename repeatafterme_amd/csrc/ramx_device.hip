@@ -153,7 +153,7 @@ extern "C" int ramx_dev_create(int ordinal, ramx_dev **out)
   CRCHK(hipHostMalloc((void **)&d->h_ctl, 4 * sizeof(RamxCtl), hipHostMallocDefault));
   CRCHK(hipMalloc((void **)&d->d_sums, (3 * NSHARD * 4 + 8) * sizeof(long long)));
   CRCHK(hipMalloc((void **)&d->d_ctl, 2 * sizeof(RamxCtl)));
-  CRCHK(hipMalloc((void **)&d->d_vote, 3 * NSHARD * sizeof(PShard)));
+  CRCHK(hipMalloc((void **)&d->d_vote, RAMX_CP_NSETS * NSHARD * sizeof(PShard)));   // 3 sets (persistent kernel) or 4 (cell-parallel)
   CRCHK(hipMalloc((void **)&d->d_err, 64));
 
   for (int i = 0; i < 2; i++) CRCHK(hipEventCreate(&d->ev_chk[i]));
@@ -512,6 +512,15 @@ static int prk_capacity_blocks(int *out)
   return RAMX_OK;
 }
 
+static void test_delay_rank(const ramx_dev *d)
+{
+  // test hook: RAMX_TEST_DELAY_RANK="rank:milliseconds" holds that rank back just before its single launch, so that its
+  // peers' kernels wait for its first words
+  const char *e = getenv("RAMX_TEST_DELAY_RANK");
+  int r = -1, ms = 0;
+  if (e && sscanf(e, "%d:%d", &r, &ms) == 2 && r == d->rank && ms > 0) usleep((useconds_t)ms * 1000);
+}
+
 template <int W, int BLOCK>
 static int prk_launch(ramx_dev *d, PArgs &pa, int blocks)
 {
@@ -522,6 +531,7 @@ static int prk_launch(ramx_dev *d, PArgs &pa, int blocks)
   // the runtime's cooperative queue is torn down after the tool has finalised (tools/rocprof_exit_probe.sh isolates it:
   // streaming launches exit cleanly, one cooperative launch does not, with or without ramx_dev_destroy).
   // RAMX_COOP_LAUNCH=1 restores the cooperative launch.
+  if (pa.nranks > 1) test_delay_rank(d);
   if (getenv("RAMX_COOP_LAUNCH") != NULL)
   {
     void *args[] = { (void *)&pa };
@@ -607,7 +617,13 @@ static int prk_run(ramx_dev *d, const KArgs &a, int L, bool *used)
         memset((void *)d->hostbox_host, 0, sizeof(PeerBox));
         __sync_synchronize();
       }
-      else HIPCHK(hipMemsetAsync(d->xbox, 0, sizeof(PeerBox), d->stream));
+      else
+      {
+        // complete, not just enqueued: the agreement below may be a host-only collective, and a peer that gets past it
+        // launches and writes into this box at once
+        HIPCHK(hipMemsetAsync(d->xbox, 0, sizeof(PeerBox), d->stream));
+        HIPCHK(hipStreamSynchronize(d->stream));
+      }
       return RAMX_OK;
     };
     const int lrc = local_prep();
@@ -841,14 +857,22 @@ extern "C" int ramx_dev_run_families(ramx_dev *d, const ramx_flank *flanks, int3
     memcpy(ca.tab, tab9, sizeof(ca.tab));
     ca.nranks = 1; ca.rank = 0;
     if ((rc = ensure(&d->d_devdesc, &d->cap_devdesc, sizeof(CpDevDesc) * hdev.size()))) goto done;
-    if ((rc = ensure(&d->d_vote_sets, &d->cap_vote_sets, sizeof(PShard) * 3 * NSHARD * (size_t)n_families))) goto done;
+    if ((rc = ensure(&d->d_vote_sets, &d->cap_vote_sets, sizeof(PShard) * RAMX_CP_NSETS * NSHARD * (size_t)n_families))) goto done;
     if ((rc = ensure(&d->d_err_sets, &d->cap_err_sets, 64 * (size_t)n_families))) goto done;
     {
       hipStream_t st = d->cls_stream[RAMX_NGROUP - 1];       // shares a stream with the last lane-per-flank shape, enqueued before it
       FAMCHK(hipMemcpyAsync(d->d_devdesc, hdev.data(), sizeof(CpDevDesc) * hdev.size(), hipMemcpyHostToDevice, st));
-      FAMCHK(hipMemsetAsync(d->d_vote_sets, 0, sizeof(PShard) * 3 * NSHARD * (size_t)n_families, st));
+      FAMCHK(hipMemsetAsync(d->d_vote_sets, 0, sizeof(PShard) * RAMX_CP_NSETS * NSHARD * (size_t)n_families, st));
       FAMCHK(hipMemsetAsync(d->d_err_sets, 0, 64 * (size_t)n_families, st));
       ca.dev = d->d_devdesc; ca.vote = d->d_vote_sets; ca.err = d->d_err_sets;
+#ifdef RAMX_CP_TIMING
+      if (n_cp == 0)
+      {
+        FAMCHK(hipMalloc((void **)&ca.dbg, (16 * 8 + 8) * sizeof(unsigned long long)));
+        FAMCHK(hipMemset(ca.dbg, 0, (16 * 8 + 8) * sizeof(unsigned long long)));
+        cp_dbg = ca.dbg;
+      }
+#endif
       rc = ramx_cp_launch_device(st, W, dev_k, dev_threads, dev_blocks, ca);
       if (rc != RAMX_OK) { ramx_set_error("cell-parallel multi-family device launch failed (W %d, %d workgroups)", W, dev_blocks); goto done; }
     }
@@ -964,14 +988,15 @@ extern "C" int ramx_dev_run_families(ramx_dev *d, const ramx_flank *flanks, int3
   {
     unsigned long long h[16 * 8 + 8];
     FAMCHK(hipMemcpy(h, cp_dbg, sizeof(h), hipMemcpyDeviceToHost));
-    static const char *nm[8] = { "vote read + stop rule", "lookups issued", "row update (fast)", "reductions (fast)", "masked/records/slide",
+    static const char *nm[8] = { "vote wait/read + stop rule", "(after speculative band)", "row update", "reductions", "records/slide/window",
                                  "sum+atomics+barrier", "-", "loop top" };
     const double cols = h[16 * 8] ? (double)h[16 * 8] : 1.0;
     fprintf(stderr, "CP_TIMING block 0, %.0f columns, shader clocks per column (waves 0, 1, last two):\n", cols);
     int nw = 0;
     for (int w = 0; w < 16; w++) if (h[w * 8 + 0]) nw = w + 1;
     for (int k = 0; k < 8; k++)
-      if (k != 6) fprintf(stderr, "CP_TIMING %-24s w0 %7.1f  w1 %7.1f  w%d %7.1f  w%d %7.1f\n", nm[k], h[k] / cols, h[8 + k] / cols,
+      if (k == 6) fprintf(stderr, "CP_TIMING mispredicted columns: %.0f of %.0f\n", (double)h[6], cols);
+      else fprintf(stderr, "CP_TIMING %-24s w0 %7.1f  w1 %7.1f  w%d %7.1f  w%d %7.1f\n", nm[k], h[k] / cols, h[8 + k] / cols,
                           nw > 1 ? nw - 2 : 0, h[(nw > 1 ? nw - 2 : 0) * 8 + k] / cols, nw > 0 ? nw - 1 : 0, h[(nw > 0 ? nw - 1 : 0) * 8 + k] / cols);
   }
 #endif
@@ -1055,7 +1080,13 @@ extern "C" int ramx_dev_run_direction(ramx_dev *d, ramx_run_info *info)
         memset((void *)d->hostbox_host, 0, sizeof(PeerBox));
         __sync_synchronize();
       }
-      else HIPCHK(hipMemsetAsync(d->xbox, 0, sizeof(PeerBox), d->stream));
+      else
+      {
+        // complete, not just enqueued: the agreement below may be a host-only collective, and a peer that gets past it
+        // launches and writes into this box at once
+        HIPCHK(hipMemsetAsync(d->xbox, 0, sizeof(PeerBox), d->stream));
+        HIPCHK(hipStreamSynchronize(d->stream));
+      }
       int cannot = k > 0 ? 0 : 1;
       int arc = host_allreduce_flag(d, &cannot);
       if (arc != RAMX_OK) return arc;
@@ -1095,10 +1126,11 @@ extern "C" int ramx_dev_run_direction(ramx_dev *d, ramx_run_info *info)
           const char *tf = getenv("RAMX_TEST_FAIL_PRK_RANK");      // test hook: this rank fails where a launch error would
           if (tf && atoi(tf) == d->rank) { ramx_set_error("test hook: forced failure of the cell-parallel launch on rank %d", d->rank); return RAMX_ERR_HIP; }
         }
-        HIPCHK(hipMemsetAsync(d->d_vote, 0, 3 * NSHARD * sizeof(PShard), d->stream));
+        HIPCHK(hipMemsetAsync(d->d_vote, 0, RAMX_CP_NSETS * NSHARD * sizeof(PShard), d->stream));
         HIPCHK(hipMemsetAsync(d->d_err, 0, 64, d->stream));
         HIPCHK(hipMemsetAsync(d->d_ctl, 0, 2 * sizeof(RamxCtl), d->stream));
         HIPCHK(hipEventRecord(d->ev_begin, d->stream));
+        if (multi) test_delay_rank(d);
         int crc = ramx_cp_launch_device(d->stream, a.W, k, th, nb, ca);
         if (crc != RAMX_OK) { ramx_set_error("cell-parallel device launch failed (W %d, %d lanes per flank, %d workgroups)", a.W, k, nb); return crc; }
         HIPCHK(hipEventRecord(d->ev_end, d->stream));

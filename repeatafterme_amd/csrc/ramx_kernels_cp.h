@@ -126,6 +126,27 @@ __device__ __forceinline__ unsigned cp_byte_x4(unsigned word)
 // M[T][class]} as four int32, one ds_read_b128 per cell: the candidates' adds are then plain v_add_u32 on two vector
 // registers, which issue at twice the rate of the SDWA byte adds a packed row needs (tools/microbench/valu_rate.hip).
 // Rows of one table sit in different LDS banks, lanes reading the same class broadcast.
+// sum of a 64-bit value over each row of 16 lanes (every lane of the row gets it): xor-1, xor-2 butterflies inside quads,
+// then the mirrored half-row and the mirrored row (sums are uniform below each step, so a mirror reaches the other half)
+__device__ __forceinline__ unsigned long long cp_row_sum_u64(unsigned long long x)
+{
+#define CP_SUM_STEP(ctrl) do { \
+    const unsigned lo_ = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)x, ctrl, 0xf, 0xf, false); \
+    const unsigned hi_ = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(x >> 32), ctrl, 0xf, 0xf, false); \
+    x += ((unsigned long long)hi_ << 32) | lo_; } while (0)
+  CP_SUM_STEP(0xB1);     // quad_perm [1,0,3,2]
+  CP_SUM_STEP(0x4E);     // quad_perm [2,3,0,1]
+  CP_SUM_STEP(0x141);    // row_half_mirror
+  CP_SUM_STEP(0x140);    // row_mirror
+#undef CP_SUM_STEP
+  return x;
+}
+__device__ __forceinline__ unsigned long long cp_readlane_u64(unsigned long long x, int l)
+{
+  return ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(x >> 32), l) << 32) |
+         (unsigned)__builtin_amdgcn_readlane((int)(unsigned)x, l);
+}
+
 struct CpTabs
 {
   int4 cand[16];
@@ -254,10 +275,12 @@ __device__ __forceinline__ void cp_update(const CpLane &ln, const int go, const 
 
 // Best cell of row r (value, lowest cell on ties: bnw_extend.c:1020-1024) and the best cells of the four candidate rows
 // r+1 (chain-free rule of ramx_kernels_common.h), reduced over the group: every lane returns the same values.
-template <int W, int K, bool G>
+struct CpNoHook { __device__ __forceinline__ void operator()() const {} };
+template <int W, int K, bool G, class Hook = CpNoHook>
 __device__ __forceinline__ void cp_reduce(const CpLane &ln, const CpTabs &tabs, const unsigned (&AE)[CpCfg<W, K>::NA],
                                           const unsigned (&AO)[CpCfg<W, K>::NA], const int (&m)[CpCfg<W, K>::C],
-                                          const int (&e)[CpCfg<W, K>::C], int &bestF, int &jbest, int (&bestA)[4])
+                                          const int (&e)[CpCfg<W, K>::C], int &bestF, int &jbest, int (&bestA)[4],
+                                          Hook &&before_allmax = CpNoHook())
 {
   typedef CpCfg<W, K> Cfg;
   constexpr int C = Cfg::C, IB = Cfg::IB;
@@ -301,6 +324,7 @@ __device__ __forceinline__ void cp_reduce(const CpLane &ln, const CpTabs &tabs, 
   if (!G) kb = ln.pDead ? CP_IMIN : kb;
   kb += ln.keyfix;                                               // low byte: 255 - j of the block's best cell
   int r0 = imax(bA[0], mE), r1 = imax(bA[1], mE), r2 = imax(bA[2], mE), r3 = imax(bA[3], mE);
+  before_allmax();
   cp_allmax5<K>(r0, r1, r2, r3, kb);
   bestA[0] = r0; bestA[1] = r1; bestA[2] = r2; bestA[3] = r3;
   bestF = kb >> 8;
@@ -315,6 +339,9 @@ __device__ __forceinline__ void cp_reduce(const CpLane &ln, const CpTabs &tabs, 
 //                 workgroup adds its four partial sums, tagged with an arrival ticket, into one of 32 shards; wave 0 of
 //                 every workgroup polls the shards of the column it is about to start).  Single GPU only.
 // ------------------------------------------------------------------------------------------
+#ifndef CP_LATE_POLL
+#define CP_LATE_POLL 1     // second poll of the ticket words during the speculative band (0: A/B builds)
+#endif
 #ifdef RAMX_CP_TIMING
 #define CP_TICK(k) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
                         __builtin_amdgcn_sched_barrier(0); tsum[k] += t_ - tlast; tlast = t_; } while (0)
@@ -356,7 +383,7 @@ __global__ __launch_bounds__((CpCfg<W, K>::MAXT > 0 ? CpCfg<W, K>::MAXT : 64), C
   }
   else fd = a.fam[blockIdx.x];
   const int wg = DEV ? dd.b : 0;                     // index of this workgroup inside its flank set
-  PShard *const vote = a.vote + (size_t)dd.id * 3 * NSHARD;      // DEV only
+  PShard *const vote = a.vote + (size_t)dd.id * RAMX_CP_NSETS * NSHARD;      // DEV only
   unsigned *const errw = a.err + (size_t)dd.id * 16;
   const int f = threadIdx.x / K;                     // flank inside the family / workgroup
   const bool live = wave * FPW < fd.nx;              // wave-uniform: does this wave hold any flank?
@@ -480,8 +507,13 @@ __global__ __launch_bounds__((CpCfg<W, K>::MAXT > 0 ? CpCfg<W, K>::MAXT : 64), C
   // (r+2) % 3 (last read at the top of column r-1, next added to during column r+1; the barrier at the end of every
   // column separates the three uses).
   // Device-wide vote (DEV = true): the waves add into the workgroup's partial sums [(r+1) & 1]; after the barrier four
-  // threads forward them, with the arrival ticket, to this workgroup's shard of device set (r+1) % 3 and clear the other
+  // threads forward them, with the arrival ticket, to this workgroup's shard of device set (r+1) % 4 and clear the other
   // buffer; every wave reads the sums it has just helped to build as the workgroup's PREDICTION of the next vote.
+  // Four device sets rotate.  Workgroup 0 clears the set of row r+3 in column r, once it has seen every ticket of row r
+  // (so everybody has finished reading row r-1, the set's previous user).  The first adds to that set come from
+  // workgroups that have seen workgroup 0's ticket for row r+2, which wave 0 of workgroup 0 sends at the end of its
+  // column r+1 -- after its own wait_vote(r+1), which begins by draining the wave's outstanding stores.  The clear is
+  // therefore complete a column before it has to be, and nobody stalls for it.
   auto publish = [&](int r, unsigned (&contrib)[4]) __attribute__((always_inline))
   {
     if (live)
@@ -498,12 +530,11 @@ __global__ __launch_bounds__((CpCfg<W, K>::MAXT > 0 ? CpCfg<W, K>::MAXT : 64), C
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (DEV)
     {
-      if (wg == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // workgroup 0: its clearing stores first
       if (threadIdx.x < 4)
       {
         const unsigned long long t = sm.vote[(r + 1) & 1][threadIdx.x];
         sm.vote[r & 1][threadIdx.x] = 0ULL;          // the OTHER buffer: read by everybody a column ago, added to again after the next barrier
-        PShard *sh = vote + (size_t)((r + 4) % 3) * NSHARD + (wg % NSHARD);
+        PShard *sh = vote + (size_t)((r + 1) & (RAMX_CP_NSETS - 1)) * NSHARD + (wg % NSHARD);
         __hip_atomic_fetch_add(&sh->word[threadIdx.x], t + PRK_BIAS + PRK_TICKET, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
@@ -511,17 +542,38 @@ __global__ __launch_bounds__((CpCfg<W, K>::MAXT > 0 ? CpCfg<W, K>::MAXT : 64), C
   // DEV: wave 0 waits until every workgroup's contribution to the vote of row r has arrived (bounded spin), folds the 32
   // shards and leaves the four sums in sm.vote[2]; returns after the workgroup barrier.  Same protocol and encoding as
   // ramx_persistent_kernel.
-  auto wait_vote = [&](int r) __attribute__((always_inline))
+  // the two ticket words lane (shard + 32 * half) watches for row r
+  auto vote_src = [&](int r) __attribute__((always_inline)) -> const unsigned long long *
+  {
+    const int sidx = lane & (NSHARD - 1), half = lane >> 5;
+    return &vote[(size_t)(r & (RAMX_CP_NSETS - 1)) * NSHARD + sidx].word[2 * half];
+  };
+  auto wait_vote = [&](int r, unsigned long long e0, unsigned long long e1, unsigned long long e2, unsigned long long e3) __attribute__((always_inline))
   {
     if (wave == 0)
     {
-      const int sidx = lane & (NSHARD - 1), half = lane >> 5;
-      const unsigned long long *src = &vote[(size_t)(r % 3) * NSHARD + sidx].word[2 * half];
+      const unsigned long long *src = vote_src(r);
       unsigned spins = 0;
-      bool done = my_shard_blocks <= 0;
-      unsigned long long x0 = 0, x1 = 0;
+      // workgroup 0: the clearing stores of the previous column (set of row r+2) are complete before this wave sends
+      // its next ticket (see publish)
+      if (wg == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // (e0, e1), (e2, e3): polls issued during the speculative band (0 when there was none); the later one is usually
+      // complete.  Tickets only grow within a row, so whichever sample is complete holds the final sums.
+      unsigned long long x0 = e0, x1 = e1;
+#ifdef CP_PROBE_NO_WAIT          // timing probe only (wrong results): whatever has arrived is the vote
+      bool done = true;
+#else
+      bool done = my_shard_blocks <= 0 ||
+                  ((x0 >> 54) >= (unsigned long long)my_shard_blocks && (x1 >> 54) >= (unsigned long long)my_shard_blocks);
+      if (!done)
+      {
+        x0 = e2; x1 = e3;
+        done = (x0 >> 54) >= (unsigned long long)my_shard_blocks && (x1 >> 54) >= (unsigned long long)my_shard_blocks;
+      }
+#endif
       for (;;)
       {
+        if (__all(done)) break;
         if (!done)
         {
           typedef unsigned v4u __attribute__((ext_vector_type(4)));
@@ -539,22 +591,26 @@ __global__ __launch_bounds__((CpCfg<W, K>::MAXT > 0 ? CpCfg<W, K>::MAXT : 64), C
         }
         __builtin_amdgcn_s_sleep(1);
       }
-      long long y0 = 0, y1 = 0;
-      if (my_shard_blocks > 0 && !failed)
+      // fold the shards: raw words first (sum + bias and ticket fields are both additive: at most 256 tickets, ten bits),
+      // rows of 16 lanes with DPP butterflies, the four rows on the scalar unit; one decode per word at the end
+      if (my_shard_blocks <= 0 || failed) { x0 = 0; x1 = 0; }
+      x0 = cp_row_sum_u64(x0); x1 = cp_row_sum_u64(x1);
+      long long v[4];                                              // this GPU's totals
       {
-        y0 = (long long)(x0 & (PRK_TICKET - 1)) - (long long)(x0 >> 54) * (long long)PRK_BIAS;
-        y1 = (long long)(x1 & (PRK_TICKET - 1)) - (long long)(x1 >> 54) * (long long)PRK_BIAS;
+        const unsigned long long t0 = cp_readlane_u64(x0, 0) + cp_readlane_u64(x0, 16), t1 = cp_readlane_u64(x1, 0) + cp_readlane_u64(x1, 16);
+        const unsigned long long t2 = cp_readlane_u64(x0, 32) + cp_readlane_u64(x0, 48), t3 = cp_readlane_u64(x1, 32) + cp_readlane_u64(x1, 48);
+        v[0] = (long long)(t0 & (PRK_TICKET - 1)) - (long long)(t0 >> 54) * (long long)PRK_BIAS;
+        v[1] = (long long)(t1 & (PRK_TICKET - 1)) - (long long)(t1 >> 54) * (long long)PRK_BIAS;
+        v[2] = (long long)(t2 & (PRK_TICKET - 1)) - (long long)(t2 >> 54) * (long long)PRK_BIAS;
+        v[3] = (long long)(t3 & (PRK_TICKET - 1)) - (long long)(t3 >> 54) * (long long)PRK_BIAS;
       }
-#pragma unroll
-      for (int mm = 16; mm >= 1; mm >>= 1) { y0 += __shfl_xor(y0, mm, 64); y1 += __shfl_xor(y1, mm, 64); }
-      long long v[4] = { __shfl(y0, 0, 64), __shfl(y1, 0, 64), __shfl(y0, 32, 64), __shfl(y1, 32, 64) };   // this GPU's totals
       if (a.nranks > 1 && !failed)
       {
         // ---- cross-device step (flanks sharded over ranks).  Workgroup 0 of every rank stores its rank's four totals,
         // tagged with the column number, into slot [r % 3][rank] of every OTHER rank's mailbox (system-scope stores over
         // xGMI, or PCIe for the host-memory boxes); every workgroup adds the other ranks' words to the local totals it has
         // just folded itself -- the local part never takes the detour through a mailbox.
-        const unsigned long long tag = (unsigned long long)(r & 0xffff) << 48;
+        const unsigned long long tag = (unsigned long long)((r + PEER_TAG_OFFSET) & 0xffff) << 48;
         const bool other = lane < a.nranks && lane != a.rank;
         if (wg == 0 && other)
         {
@@ -642,16 +698,23 @@ __global__ __launch_bounds__((CpCfg<W, K>::MAXT > 0 ? CpCfg<W, K>::MAXT : 64), C
   // flanks enter or leave the band's range): with both variants in ONE loop body the register allocator needed ~45
   // registers more than the larger of the two.  Returns true when the column loop ends.
   // the band of one row against winner b: row r from row r-1, best cell of row r, best cells of the candidate rows r+1
-  auto band = [&](const int r, const int b, auto gc, int &bestF, int &jb, int (&bestA)[4]) __attribute__((always_inline))
+  auto band = [&](const int r, const int b, auto gc, int &bestF, int &jb, int (&bestA)[4], auto &&between, auto &&late) __attribute__((always_inline))
   {
     constexpr bool G = decltype(gc)::value;
+#ifdef CP_PROBE_NO_BAND          // timing probe only (wrong results): the column without its arithmetic
+    between();
+    bestF = r; jb = W;
+    return;
+#endif
     int sFv[C];
     winner_scores(AE, AO, b, sFv);
     cp_update<W, K, G>(ln, vgo, vge, a.go + (r + 1) * a.ge /* edge fill, first W rows only (set_masks: iWr) */, sFv, m, e);
     CP_TICK(2);                  // row update
-    cp_reduce<W, K, G>(ln, sm.tabs, AE, AO, m, e, bestF, jb, bestA);
+    between();
+    cp_reduce<W, K, G>(ln, sm.tabs, AE, AO, m, e, bestF, jb, bestA, late);
     CP_TICK(3);                  // reductions
   };
+  auto nothing = []() __attribute__((always_inline)) {};
   auto column = [&](const int r, auto gc) __attribute__((always_inline)) -> bool
   {
     constexpr bool G = decltype(gc)::value;
@@ -662,6 +725,7 @@ __global__ __launch_bounds__((CpCfg<W, K>::MAXT > 0 ? CpCfg<W, K>::MAXT : 64), C
     constexpr bool SPEC = DEV && C <= 11;
     CP_TICK(7);                  // barrier released .. loop top
     int bestA[4] = { 0, 0, 0, 0 }, bestF = 0, jb = 0, guess = -1;
+    unsigned long long early0 = 0, early1 = 0, early2 = 0, early3 = 0;
     int sm_[SPEC ? C : 1], se_[SPEC ? C : 1];
     if (G && live) set_masks(r);
     if constexpr (SPEC)
@@ -682,12 +746,32 @@ __global__ __launch_bounds__((CpCfg<W, K>::MAXT > 0 ? CpCfg<W, K>::MAXT : 64), C
       {
         static_for([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value; sm_[i] = m[i]; se_[i] = e[i]; },
                    std::make_integer_sequence<int, C>{});
-        band(r, guess, gc, bestF, jb, bestA);
+        // wave 0 looks at the ticket words twice during the band (after the row update and before the wave-wide
+        // reductions): the loads travel while the band runs.  The other workgroups' adds were issued at the end of the
+        // previous column and land about half a band later; a poll sent just after that returns as the band ends.
+        band(r, guess, gc, bestF, jb, bestA, [&]() __attribute__((always_inline))
+        {
+          if (wave == 0 && my_shard_blocks > 0)
+          {
+            const unsigned long long *src = vote_src(r);
+            early0 = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            early1 = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }, [&]() __attribute__((always_inline))
+        {
+          if (CP_LATE_POLL && wave == 0 && my_shard_blocks > 0)
+          {
+            const unsigned long long *src = vote_src(r);
+            early2 = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            early3 = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        });
       }
     }
+    CP_TICK(1);                  // DEV: speculative band
     if (DEV)
     {
-      wait_vote(r);
+      wait_vote(r, early0, early1, early2, early3);
       if (__builtin_amdgcn_readfirstlane(sm.fail)) { failed = 1; return true; }
     }
     // vote of row r: block-local (added during the previous column).  The sums are non-negative: they are compared
@@ -720,9 +804,9 @@ __global__ __launch_bounds__((CpCfg<W, K>::MAXT > 0 ? CpCfg<W, K>::MAXT : 64), C
     else if (wg == 0)
     {
       if (threadIdx.x == 0) a.cons_out[(size_t)dd.id * a.L + r] = (signed char)besta;
-      if (threadIdx.x < NSHARD)     // workgroup 0 clears the device set of row r+2 (protocol: ramx_kernels_resident.h)
+      if (threadIdx.x < NSHARD)     // workgroup 0 clears the device set of row r+3 (see publish)
       {
-        PShard *z = vote + (size_t)((r + 2) % 3) * NSHARD + threadIdx.x;
+        PShard *z = vote + (size_t)((r + 3) & (RAMX_CP_NSETS - 1)) * NSHARD + threadIdx.x;
 #pragma unroll
         for (int k = 0; k < 4; k++) __hip_atomic_store(&z->word[k], 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
@@ -731,12 +815,12 @@ __global__ __launch_bounds__((CpCfg<W, K>::MAXT > 0 ? CpCfg<W, K>::MAXT : 64), C
     CP_TICK(0);                  // vote read, stop rule
     if (live)
     {
-      if constexpr (!SPEC) band(r, besta, gc, bestF, jb, bestA);
+      if constexpr (!SPEC) band(r, besta, gc, bestF, jb, bestA, nothing, nothing);
       else if (guess != besta)
       {
         static_for([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value; m[i] = sm_[i]; e[i] = se_[i]; },
                    std::make_integer_sequence<int, C>{});
-        band(r, besta, gc, bestF, jb, bestA);
+        band(r, besta, gc, bestF, jb, bestA, nothing, nothing);
 #ifdef RAMX_CP_TIMING
         tsum[6] += 1;            // mispredicted columns
 #endif

@@ -38,6 +38,11 @@ struct PShard { unsigned long long word[4]; unsigned long long pad[4]; };   // 6
 // box until all ranks' words of this column are there.  3 sets rotate exactly like the vote shards.
 #define RAMX_MAX_RANKS 16
 struct PeerBox { unsigned long long slot[3][RAMX_MAX_RANKS][4]; unsigned long long token[RAMX_MAX_RANKS]; };
+// a word's tag is the low 16 bits of (row + 1): a cleared slot (tag 0) is never taken for row 0's word by a rank that
+// looks before its peer has written
+#ifndef PEER_TAG_OFFSET
+#define PEER_TAG_OFFSET 1
+#endif
 #define PEER_VBIAS (1LL << 46)
 #define PEER_VMASK ((1ULL << 48) - 1)
 
@@ -475,7 +480,7 @@ __global__ __launch_bounds__(BLOCK, 2) void ramx_persistent_kernel(const PArgs a
       if (a.nranks > 1 && r > 0 && !failed)
       {
         // ---- cross-device step: v[] is this rank's total (identical in all lanes) -----------
-        const unsigned long long tag = (unsigned long long)(r & 0xffff) << 48;
+        const unsigned long long tag = (unsigned long long)((r + PEER_TAG_OFFSET) & 0xffff) << 48;
         if (blockIdx.x == 0 && lane < a.nranks)
         {
           PeerBox *pb = a.peers[lane];

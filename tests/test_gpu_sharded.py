@@ -21,7 +21,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out, peer=False, W=20, kind="", fail_rank=None, no_cp=False):
+def _worker(rank, world, port, out, peer=False, W=20, kind="", fail_rank=None, no_cp=False, delay=None):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -50,6 +50,8 @@ def _worker(rank, world, port, out, peer=False, W=20, kind="", fail_rank=None, n
     p = po.Params.named("14p43g", bandwidth=W, L=150, when_to_stop=25)
     if fail_rank is not None:
         os.environ["RAMX_TEST_FAIL_PRK_RANK"] = str(fail_rank)
+    if delay is not None:
+        os.environ["RAMX_TEST_DELAY_RANK"] = delay      # "rank:ms": that rank launches late, its peers' kernels wait for its words
     if no_cp:
         os.environ["RAMX_NO_CP_DEVICE"] = "1"           # the lane-per-flank persistent kernel instead of the cell-parallel one
     dev = Device(0)
@@ -127,6 +129,30 @@ def test_two_ranks_cross_device_persistent_path(W, kind, no_cp):
         assert rets == [(r1.ret, r1.rows_executed), (r0.ret, r0.rows_executed)], rank
         assert np.array_equal(mm, m) and np.array_equal(ll, c.left_len) and np.array_equal(rl, c.right_len)
         assert np.array_equal(sc, c.score)
+
+
+@pytest.mark.parametrize("no_cp", [False, True], ids=["cell-parallel", "lane-per-flank"])
+@pytest.mark.parametrize("late", [0, 1])
+def test_two_ranks_one_launches_late(late, no_cp):
+    """One rank's single launch starts 30 ms after the other's: the early kernel reaches the exchange of row 0 long before
+    its peer has written anything.  A cleared mailbox slot must not pass for row 0's word (the tag is row + 1), and the
+    mailbox is cleared before -- not while -- the peer may write into it."""
+    from oracle import pyoracle as po
+    from repeatafterme_amd.datamodel import new_master
+    from repeatafterme_amd.synth import synth_family
+    world = 2
+    out = mp.Manager().dict()
+    mp.spawn(_worker, args=(world, _free_port(), out, True, 14, "device", None, no_cp, f"{late}:30"), nprocs=world, join=True)
+    fs = synth_family(333, 150, 14, K=100, seed=12, both_sides=True, minus_frac=0.3, n_run_frac=0.1)
+    p = po.Params.named("14p43g", bandwidth=14, L=150, when_to_stop=25)
+    c = fs.cores.copy(); m = new_master(p.L)
+    r1 = po.oracle_extend(1, c, fs.sequence, m, p); r0 = po.oracle_extend(0, c, fs.sequence, m, p)
+    for rank in range(world):
+        rets, mm, ll, rl, sc, enabled, used, lanes = out[rank]
+        assert enabled and used == 1 and (lanes == 1) == no_cp
+        assert rets == [(r1.ret, r1.rows_executed), (r0.ret, r0.rows_executed)], rank
+        assert np.array_equal(mm, m) and np.array_equal(ll, c.left_len) and np.array_equal(rl, c.right_len)
+        assert np.array_equal(sc, c.score), np.flatnonzero(sc != c.score)[:10]
 
 
 def test_rank_local_failure_after_agreement_falls_back_on_all_ranks():
