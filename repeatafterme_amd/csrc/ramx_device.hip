@@ -868,8 +868,8 @@ extern "C" int ramx_dev_run_families(ramx_dev *d, const ramx_flank *flanks, int3
 #ifdef RAMX_CP_TIMING
       if (n_cp == 0)
       {
-        FAMCHK(hipMalloc((void **)&ca.dbg, (16 * 8 + 8) * sizeof(unsigned long long)));
-        FAMCHK(hipMemset(ca.dbg, 0, (16 * 8 + 8) * sizeof(unsigned long long)));
+        FAMCHK(hipMalloc((void **)&ca.dbg, (16 * 16 + 8) * sizeof(unsigned long long)));
+        FAMCHK(hipMemset(ca.dbg, 0, (16 * 16 + 8) * sizeof(unsigned long long)));
         cp_dbg = ca.dbg;
       }
 #endif
@@ -899,8 +899,8 @@ extern "C" int ramx_dev_run_families(ramx_dev *d, const ramx_flank *flanks, int3
       d->cpstate_W = W; d->cpstate_n = Np;
     }
 #ifdef RAMX_CP_TIMING
-    FAMCHK(hipMalloc((void **)&ca.dbg, (16 * 8 + 8) * sizeof(unsigned long long)));
-    FAMCHK(hipMemset(ca.dbg, 0, (16 * 8 + 8) * sizeof(unsigned long long)));
+    FAMCHK(hipMalloc((void **)&ca.dbg, (16 * 16 + 8) * sizeof(unsigned long long)));
+    FAMCHK(hipMemset(ca.dbg, 0, (16 * 16 + 8) * sizeof(unsigned long long)));
     cp_dbg = ca.dbg;
 #endif
     for (int c = 0; c < RAMX_CP_NCLASS; c++)
@@ -986,18 +986,19 @@ extern "C" int ramx_dev_run_families(ramx_dev *d, const ramx_flank *flanks, int3
 #ifdef RAMX_CP_TIMING
   if (cp_dbg)
   {
-    unsigned long long h[16 * 8 + 8];
+    unsigned long long h[16 * 16 + 8];
     FAMCHK(hipMemcpy(h, cp_dbg, sizeof(h), hipMemcpyDeviceToHost));
-    static const char *nm[8] = { "vote wait/read + stop rule", "(after speculative band)", "row update", "reductions", "records/slide/window",
-                                 "sum+atomics+barrier", "-", "loop top" };
-    const double cols = h[16 * 8] ? (double)h[16 * 8] : 1.0;
+    static const char *nm[12] = { "vote read + stop rule", "(after speculative band)", "row update", "reductions", "records/slide/window",
+                                  "sum+atomics+barrier", "-", "loop top", "wait: drain", "wait: samples + polling", "wait: fold",
+                                  "wait: LDS + barrier" };
+    const double cols = h[16 * 16] ? (double)h[16 * 16] : 1.0;
     fprintf(stderr, "CP_TIMING block 0, %.0f columns, shader clocks per column (waves 0, 1, last two):\n", cols);
     int nw = 0;
-    for (int w = 0; w < 16; w++) if (h[w * 8 + 0]) nw = w + 1;
-    for (int k = 0; k < 8; k++)
+    for (int w = 0; w < 16; w++) if (h[w * 16 + 0]) nw = w + 1;
+    for (int k = 0; k < 12; k++)
       if (k == 6) fprintf(stderr, "CP_TIMING mispredicted columns: %.0f of %.0f\n", (double)h[6], cols);
-      else fprintf(stderr, "CP_TIMING %-24s w0 %7.1f  w1 %7.1f  w%d %7.1f  w%d %7.1f\n", nm[k], h[k] / cols, h[8 + k] / cols,
-                          nw > 1 ? nw - 2 : 0, h[(nw > 1 ? nw - 2 : 0) * 8 + k] / cols, nw > 0 ? nw - 1 : 0, h[(nw > 0 ? nw - 1 : 0) * 8 + k] / cols);
+      else fprintf(stderr, "CP_TIMING %-24s w0 %7.1f  w1 %7.1f  w%d %7.1f  w%d %7.1f\n", nm[k], h[k] / cols, h[16 + k] / cols,
+                          nw > 1 ? nw - 2 : 0, h[(nw > 1 ? nw - 2 : 0) * 16 + k] / cols, nw > 0 ? nw - 1 : 0, h[(nw > 0 ? nw - 1 : 0) * 16 + k] / cols);
   }
 #endif
   hctl = (RamxCtl *)malloc(sizeof(RamxCtl) * n_families);

@@ -438,6 +438,11 @@ __global__ __launch_bounds__((CpCfg<W, K>::MAXT > 0 ? CpCfg<W, K>::MAXT : 64), C
       w[k] = a.bases[(size_t)wi * a.Np + n];
     }, std::make_integer_sequence<int, NWL + 1>{});
   }
+  unsigned wpre;                                     // the word the next slide brings in (see finish_column)
+  {
+    const int wn = (s >> 3) + 1 + NWL;
+    wpre = a.bases[(size_t)(wn < a.KW ? wn : a.KW - 1) * a.Np + n];
+  }
   // ---- pieces of a column --------------------------------------------------------------------
   // the lane's base window as LDS offsets: byte b of AE[k] / AO[k] = 4 * class of cell 8k + 2b / 8k + 2b + 1 (cells 0 .. C:
   // cell C is the candidates' base of the block's last cell).  They depend only on the base stream and are computed at
@@ -494,15 +499,20 @@ __global__ __launch_bounds__((CpCfg<W, K>::MAXT > 0 ? CpCfg<W, K>::MAXT : 64), C
       const int b = bestA[c] < 0 ? 0 : bestA[c];
       contrib[c] = active ? (unsigned)((b >= capv) ? b : capv) : 0u;
     }
+    // The window slides by one word when the lane's nibble pointer crosses a word (lanes of a flank do so in different
+    // columns, so some lane slides in every column).  The incoming word was loaded a column ago (wpre): every lane loads,
+    // in every column, the word its next slide will bring in, so nothing ever waits for a load it has just issued.
     s++;
-    if ((s & 7) == 0)
-    {
-      static_for([&](auto kc) __attribute__((always_inline)) { constexpr int k = decltype(kc)::value; w[k] = w[k + 1]; },
-                 std::make_integer_sequence<int, NWL>{});
-      const int wn = (s >> 3) + NWL;
-      w[NWL] = a.bases[(size_t)(wn < a.KW ? wn : a.KW - 1) * a.Np + n];
-    }
+    const bool slide = (s & 7) == 0;
+    static_for([&](auto kc) __attribute__((always_inline)) { constexpr int k = decltype(kc)::value; w[k] = slide ? w[k + 1] : w[k]; },
+               std::make_integer_sequence<int, NWL>{});
+    w[NWL] = slide ? wpre : w[NWL];
+    const int wn = (s >> 3) + 1 + NWL;
+    wpre = a.bases[(size_t)(wn < a.KW ? wn : a.KW - 1) * a.Np + n];
   };
+#ifdef RAMX_CP_TIMING
+  unsigned long long tsum[16] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }, tlast = __builtin_amdgcn_s_memtime();
+#endif
   // Block-local vote (DEV = false): three sets rotate -- column r reads set r % 3, adds to set (r+1) % 3 and clears set
   // (r+2) % 3 (last read at the top of column r-1, next added to during column r+1; the barrier at the end of every
   // column separates the three uses).
@@ -557,6 +567,7 @@ __global__ __launch_bounds__((CpCfg<W, K>::MAXT > 0 ? CpCfg<W, K>::MAXT : 64), C
       // workgroup 0: the clearing stores of the previous column (set of row r+2) are complete before this wave sends
       // its next ticket (see publish)
       if (wg == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      CP_TICK(8);                // wave 0: drain
       // (e0, e1), (e2, e3): polls issued during the speculative band (0 when there was none); the later one is usually
       // complete.  Tickets only grow within a row, so whichever sample is complete holds the final sums.
       unsigned long long x0 = e0, x1 = e1;
@@ -591,6 +602,7 @@ __global__ __launch_bounds__((CpCfg<W, K>::MAXT > 0 ? CpCfg<W, K>::MAXT : 64), C
         }
         __builtin_amdgcn_s_sleep(1);
       }
+      CP_TICK(9);                // wave 0: early samples, polling
       // fold the shards: raw words first (sum + bias and ticket fields are both additive: at most 256 tickets, ten bits),
       // rows of 16 lanes with DPP butterflies, the four rows on the scalar unit; one decode per word at the end
       if (my_shard_blocks <= 0 || failed) { x0 = 0; x1 = 0; }
@@ -655,6 +667,7 @@ __global__ __launch_bounds__((CpCfg<W, K>::MAXT > 0 ? CpCfg<W, K>::MAXT : 64), C
         for (int k = 0; k < 4; k++)
           v[k] += wave_sum_ll((other && !failed) ? (long long)(yy[k] & PEER_VMASK) - PEER_VBIAS : 0LL);
       }
+      CP_TICK(10);               // wave 0: fold (and the cross-device step)
       if (lane == 0)
       {
         sm.vote[2][0] = (unsigned long long)v[0]; sm.vote[2][1] = (unsigned long long)v[1];
@@ -664,6 +677,7 @@ __global__ __launch_bounds__((CpCfg<W, K>::MAXT > 0 ? CpCfg<W, K>::MAXT : 64), C
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    CP_TICK(11);                 // LDS write, barrier (waves other than 0: the whole wait)
   };
   unsigned AE[NA], AO[NA];
   static_for([&](auto kc) __attribute__((always_inline)) { constexpr int k = decltype(kc)::value; AE[k] = 0; AO[k] = 0; },
@@ -691,9 +705,6 @@ __global__ __launch_bounds__((CpCfg<W, K>::MAXT > 0 ? CpCfg<W, K>::MAXT : 64), C
     }
     publish(-1, contrib);
   }
-#ifdef RAMX_CP_TIMING
-  unsigned long long tsum[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, tlast = __builtin_amdgcn_s_memtime();
-#endif
   // One column.  The fast and the masked variant are two separate loops below (a wave switches between them when its
   // flanks enter or leave the band's range): with both variants in ONE loop body the register allocator needed ~45
   // registers more than the larger of the two.  Returns true when the column loop ends.
@@ -868,8 +879,8 @@ __global__ __launch_bounds__((CpCfg<W, K>::MAXT > 0 ? CpCfg<W, K>::MAXT : 64), C
   if (a.dbg != NULL && blockIdx.x == 0 && lane == 0)
   {
 #pragma unroll
-    for (int k = 0; k < 8; k++) a.dbg[wave * 8 + k] = tsum[k];
-    if (wave == 0) a.dbg[16 * 8] = (unsigned long long)rows_done;
+    for (int k = 0; k < 16; k++) a.dbg[wave * 16 + k] = tsum[k];
+    if (wave == 0) a.dbg[16 * 16] = (unsigned long long)rows_done;
   }
 #endif
   if (live && a.state_out != NULL && active)
