@@ -108,7 +108,7 @@ int ramx_cp_launch_families(hipStream_t st, int W, int K, int threads, int F, co
 }
 
 // ---- device-wide mode ----------------------------------------------------------------------------
-// One 512-thread workgroup per CU at most (the vote barrier wants few participants and the launch must be co-resident).
+// One workgroup (512 threads unless tuned) per CU at most (the vote barrier wants few participants and the launch must be co-resident).
 // Lanes per flank: as many as keep the set within `cus` workgroups, but not more than a family of that size would get.
 int ramx_cp_device_plan(int W, int n, int cus, int *K, int *threads, int *blocks)
 {
@@ -123,7 +123,10 @@ int ramx_cp_device_plan(int W, int n, int cus, int *K, int *threads, int *blocks
     if (t == 0) continue;
     const char *ft = getenv("RAMX_CP_DEV_THREADS");  // tuning hook: workgroup size of the device-wide launch
     if (ft && atoi(ft) >= 64 && atoi(ft) <= t && (atoi(ft) & 63) == 0) t = atoi(ft);
-    const int per = t / k;
+    // short blocks: wave 0 of every workgroup is the vote wave and holds no flank (RAMX_CP_SYNCW_MAXC)
+    const bool syncw = cp_cells(W, k) <= RAMX_CP_SYNCW_MAXC;
+    if (syncw && t < 128) t = 128;
+    const int per = (t - (syncw ? 64 : 0)) / k;
     const int nb = (n + per - 1) / per;
     if (nb > cus) continue;
     *K = k; *threads = t; *blocks = nb;

@@ -11,6 +11,9 @@
 // device-wide mode: rotating sets of vote shards (row r uses set r % 4; workgroup 0 clears the set of row r+3 during column r,
 // a whole column before anybody adds to it -- see publish / wait_vote in ramx_kernels_cp.h)
 #define RAMX_CP_NSETS 4
+// device-wide mode, blocks of at most this many cells per lane: wave 0 of every workgroup holds no flank (it runs the vote),
+// so a workgroup of T threads holds (T - 64) / K flanks
+#define RAMX_CP_SYNCW_MAXC 11
 
 struct CpDevDesc
 {

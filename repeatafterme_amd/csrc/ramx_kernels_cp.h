@@ -339,6 +339,9 @@ __device__ __forceinline__ void cp_reduce(const CpLane &ln, const CpTabs &tabs, 
 //                 workgroup adds its four partial sums, tagged with an arrival ticket, into one of 32 shards; wave 0 of
 //                 every workgroup polls the shards of the column it is about to start).  Single GPU only.
 // ------------------------------------------------------------------------------------------
+#ifndef CP_SYNC_FIRST_SLEEP
+#define CP_SYNC_FIRST_SLEEP 4   // s_sleep units (64 clocks) before the vote wave's first look at the tickets of a row
+#endif
 #ifndef CP_LATE_POLL
 #define CP_LATE_POLL 1     // second poll of the ticket words during the speculative band (0: A/B builds)
 #endif
@@ -357,13 +360,14 @@ __global__ __launch_bounds__((CpCfg<W, K>::MAXT > 0 ? CpCfg<W, K>::MAXT : 64), C
 {
   typedef CpCfg<W, K> Cfg;
   constexpr int B = Cfg::B, C = Cfg::C, NA = Cfg::NA, NWL = Cfg::NWL, FPW = 64 / K;
+  constexpr bool SYNCW = DEV && C <= RAMX_CP_SYNCW_MAXC;  // device-wide mode with short blocks: a dedicated vote wave, speculative columns
   static_assert(K == 2 || K == 4 || K == 8 || K == 16, "lanes per flank");
   static_assert(B <= 255, "cell index must fit the key's low byte");
   struct Smem
   {
     CpTabs tabs;                                     // first: the table rows are addressed with 16-bit immediate offsets
     unsigned long long vote[3][4];                   // DEV: [0..1] = this workgroup's partial sums (double buffered), [2] = the device-wide vote
-    int fail, pred, pad[2];                         // pred: this workgroup's own argmax for the next row (speculation)
+    int fail, dec, pad[2];                          // dec: the vote wave's decision word for the band waves (SYNCW)
   };
   __shared__ __attribute__((aligned(16))) Smem sm;
   // wave index through readfirstlane: `live` must be PROVABLY wave-uniform, or the band sits in a divergent region and
@@ -374,9 +378,9 @@ __global__ __launch_bounds__((CpCfg<W, K>::MAXT > 0 ? CpCfg<W, K>::MAXT : 64), C
   dd.first = 0; dd.nx = 0; dd.b = 0; dd.nb = 1; dd.id = 0;
   if (DEV)
   {
-    // workgroup b of a set holds blockDim / K consecutive flanks of it
+    // workgroup b of a set holds (band waves) * 64 / K consecutive flanks of it
     dd = a.dev[blockIdx.x];
-    const int per = blockDim.x / K;
+    const int per = (blockDim.x - (SYNCW ? 64 : 0)) / K;
     fd.tile0 = 0; fd.ntiles = 0; fd.id = dd.id;
     fd.nx = dd.nx - dd.b * per;                      // flanks (of this workgroup) that exist
     fd.nx = fd.nx < 0 ? 0 : (fd.nx > per ? per : fd.nx);
@@ -385,10 +389,11 @@ __global__ __launch_bounds__((CpCfg<W, K>::MAXT > 0 ? CpCfg<W, K>::MAXT : 64), C
   const int wg = DEV ? dd.b : 0;                     // index of this workgroup inside its flank set
   PShard *const vote = a.vote + (size_t)dd.id * RAMX_CP_NSETS * NSHARD;      // DEV only
   unsigned *const errw = a.err + (size_t)dd.id * 16;
-  const int f = threadIdx.x / K;                     // flank inside the family / workgroup
-  const bool live = wave * FPW < fd.nx;              // wave-uniform: does this wave hold any flank?
-  const bool active = f < fd.nx;
-  const int n = DEV ? dd.first + wg * (blockDim.x / K) + (live ? f : 0) : fd.tile0 * 64 + (live ? f : 0);
+  // SYNCW: wave 0 holds no flank -- it runs the device-wide vote (sync_column below) while waves 1.. run the band
+  const int f = SYNCW ? (wave > 0 ? ((int)threadIdx.x - 64) / K : 0) : threadIdx.x / K;   // flank inside the family / workgroup
+  const bool live = SYNCW ? (wave > 0 && (wave - 1) * FPW < fd.nx) : (wave * FPW < fd.nx);  // wave-uniform: does this wave hold any flank?
+  const bool active = live && f < fd.nx;
+  const int n = DEV ? dd.first + wg * ((int)(blockDim.x - (SYNCW ? 64 : 0)) / K) + (live ? f : 0) : fd.tile0 * 64 + (live ? f : 0);
   const int my_shard_blocks = DEV ? (dd.nb - (lane & (NSHARD - 1)) + NSHARD - 1) / NSHARD : 0;   // wave 0: blocks arriving on shard lane & 31
   int failed = 0;
 
@@ -490,15 +495,19 @@ __global__ __launch_bounds__((CpCfg<W, K>::MAXT > 0 ? CpCfg<W, K>::MAXT : 64), C
   };
   // clamp at 0, cap from below by high + CAPPENALTY (ram_extend.c:1042, 1052-1062); then slide the window by one base:
   // one new word every eighth column, loaded a whole word ahead of its first use
-  auto finish_column = [&](const int (&bestA)[4], unsigned (&contrib)[4]) __attribute__((always_inline))
+  // contributions of this flank to the vote of the next row (ram_extend.c:1062-1079), given the flank's best score so far
+  auto contributions = [&](const int (&bestA)[4], const int high_now, unsigned (&contrib)[4]) __attribute__((always_inline))
   {
-    const int capv = high + a.cap;
+    const int capv = high_now + a.cap;
 #pragma unroll
     for (int c = 0; c < 4; c++)
     {
       const int b = bestA[c] < 0 ? 0 : bestA[c];
       contrib[c] = active ? (unsigned)((b >= capv) ? b : capv) : 0u;
     }
+  };
+  auto slide_window = [&]() __attribute__((always_inline))
+  {
     // The window slides by one word when the lane's nibble pointer crosses a word (lanes of a flank do so in different
     // columns, so some lane slides in every column).  The incoming word was loaded a column ago (wpre): every lane loads,
     // in every column, the word its next slide will bring in, so nothing ever waits for a load it has just issued.
@@ -509,6 +518,11 @@ __global__ __launch_bounds__((CpCfg<W, K>::MAXT > 0 ? CpCfg<W, K>::MAXT : 64), C
     w[NWL] = slide ? wpre : w[NWL];
     const int wn = (s >> 3) + 1 + NWL;
     wpre = a.bases[(size_t)(wn < a.KW ? wn : a.KW - 1) * a.Np + n];
+  };
+  auto finish_column = [&](const int (&bestA)[4], unsigned (&contrib)[4]) __attribute__((always_inline))
+  {
+    contributions(bestA, high, contrib);
+    slide_window();
   };
 #ifdef RAMX_CP_TIMING
   unsigned long long tsum[16] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }, tlast = __builtin_amdgcn_s_memtime();
@@ -524,6 +538,12 @@ __global__ __launch_bounds__((CpCfg<W, K>::MAXT > 0 ? CpCfg<W, K>::MAXT : 64), C
   // workgroups that have seen workgroup 0's ticket for row r+2, which wave 0 of workgroup 0 sends at the end of its
   // column r+1 -- after its own wait_vote(r+1), which begins by draining the wave's outstanding stores.  The clear is
   // therefore complete a column before it has to be, and nobody stalls for it.
+  // thread k < 4 of the workgroup: word k of the workgroup's sums for row r+1, with the arrival ticket
+  auto send_words = [&](int r, unsigned long long t) __attribute__((always_inline))
+  {
+    PShard *sh = vote + (size_t)((r + 1) & (RAMX_CP_NSETS - 1)) * NSHARD + (wg % NSHARD);
+    __hip_atomic_fetch_add(&sh->word[threadIdx.x], t + PRK_BIAS + PRK_TICKET, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
   auto publish = [&](int r, unsigned (&contrib)[4]) __attribute__((always_inline))
   {
     if (live)
@@ -544,8 +564,7 @@ __global__ __launch_bounds__((CpCfg<W, K>::MAXT > 0 ? CpCfg<W, K>::MAXT : 64), C
       {
         const unsigned long long t = sm.vote[(r + 1) & 1][threadIdx.x];
         sm.vote[r & 1][threadIdx.x] = 0ULL;          // the OTHER buffer: read by everybody a column ago, added to again after the next barrier
-        PShard *sh = vote + (size_t)((r + 1) & (RAMX_CP_NSETS - 1)) * NSHARD + (wg % NSHARD);
-        __hip_atomic_fetch_add(&sh->word[threadIdx.x], t + PRK_BIAS + PRK_TICKET, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        send_words(r, t);
       }
     }
   };
@@ -558,7 +577,62 @@ __global__ __launch_bounds__((CpCfg<W, K>::MAXT > 0 ? CpCfg<W, K>::MAXT : 64), C
     const int sidx = lane & (NSHARD - 1), half = lane >> 5;
     return &vote[(size_t)(r & (RAMX_CP_NSETS - 1)) * NSHARD + sidx].word[2 * half];
   };
-  auto wait_vote = [&](int r, unsigned long long e0, unsigned long long e1, unsigned long long e2, unsigned long long e3) __attribute__((always_inline))
+  // wave 0, all lanes: add the other ranks' totals for row r to v (this rank's), exchanging through the mailboxes
+  auto cross_device = [&](const int r, long long (&v)[4]) __attribute__((always_inline))
+  {
+      // ---- cross-device step (flanks sharded over ranks).  Workgroup 0 of every rank stores its rank's four totals,
+      // tagged with the column number, into slot [r % 3][rank] of every OTHER rank's mailbox (system-scope stores over
+      // xGMI, or PCIe for the host-memory boxes); every workgroup adds the other ranks' words to the local totals it has
+      // just folded itself -- the local part never takes the detour through a mailbox.
+      const unsigned long long tag = (unsigned long long)((r + PEER_TAG_OFFSET) & 0xffff) << 48;
+      const bool other = lane < a.nranks && lane != a.rank;
+      if (wg == 0 && other)
+      {
+        PeerBox *pb = a.peers[lane];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+        {
+          if (v[k] >= PEER_VBIAS || v[k] <= -PEER_VBIAS) failed = 1;     // cannot be encoded: fail loudly
+          __hip_atomic_store(&pb->slot[r % 3][a.rank][k], tag | ((unsigned long long)(v[k] + PEER_VBIAS) & PEER_VMASK),
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+      }
+      unsigned long long yy[4] = { 0, 0, 0, 0 };
+      bool got = !other;
+      unsigned spins2 = 0;
+      const PeerBox *pollbox = (a.mirror != NULL && wg != 0) ? a.mirror : a.box;
+      for (;;)
+      {
+        if (!got)
+        {
+#pragma unroll
+          for (int k = 0; k < 4; k++) yy[k] = __hip_atomic_load(&pollbox->slot[r % 3][lane][k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          got = (yy[0] >> 48) == (tag >> 48) && (yy[1] >> 48) == (tag >> 48) && (yy[2] >> 48) == (tag >> 48) && (yy[3] >> 48) == (tag >> 48);
+          if (got && a.mirror != NULL && wg == 0)
+          {
+            // host-memory boxes: only workgroup 0 polls across PCIe; it passes every arriving word on to the local pollers
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+              __hip_atomic_store(&a.mirror->slot[r % 3][lane][k], yy[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+        if (__all(got)) break;
+        if (++spins2 > PRK_SPIN_LIMIT || ((spins2 & 1023u) == 0 && __hip_atomic_load(errw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0))
+        {
+          failed = 1;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      failed = __any(failed) ? 1 : 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        v[k] += wave_sum_ll((other && !failed) ? (long long)(yy[k] & PEER_VMASK) - PEER_VBIAS : 0LL);
+  };
+  // guess / tsend / sent (speculative columns): when the vote confirms the workgroup's guess, lanes 0..3 of wave 0 send the
+  // workgroup's sums for row r+1 (tsend, built from the speculative row) and the ticket at once -- before anything else
+  auto wait_vote = [&](int r, unsigned long long e0, unsigned long long e1, unsigned long long e2, unsigned long long e3,
+                       const int guess, const unsigned long long tsend, bool &sent) __attribute__((always_inline))
   {
     if (wave == 0)
     {
@@ -616,56 +690,18 @@ __global__ __launch_bounds__((CpCfg<W, K>::MAXT > 0 ? CpCfg<W, K>::MAXT : 64), C
         v[2] = (long long)(t2 & (PRK_TICKET - 1)) - (long long)(t2 >> 54) * (long long)PRK_BIAS;
         v[3] = (long long)(t3 & (PRK_TICKET - 1)) - (long long)(t3 >> 54) * (long long)PRK_BIAS;
       }
-      if (a.nranks > 1 && !failed)
+      if (a.nranks > 1 && !failed) cross_device(r, v);
+      if (guess >= 0 && !failed)
       {
-        // ---- cross-device step (flanks sharded over ranks).  Workgroup 0 of every rank stores its rank's four totals,
-        // tagged with the column number, into slot [r % 3][rank] of every OTHER rank's mailbox (system-scope stores over
-        // xGMI, or PCIe for the host-memory boxes); every workgroup adds the other ranks' words to the local totals it has
-        // just folded itself -- the local part never takes the detour through a mailbox.
-        const unsigned long long tag = (unsigned long long)((r + PEER_TAG_OFFSET) & 0xffff) << 48;
-        const bool other = lane < a.nranks && lane != a.rank;
-        if (wg == 0 && other)
+        int b0 = 0;
+        unsigned long long c0 = 0;     // the rule of the vote read in the column (unsigned, first maximum wins)
+#pragma unroll
+        for (int k = 0; k < 4; k++) if ((unsigned long long)v[k] > c0) { c0 = (unsigned long long)v[k]; b0 = k; }
+        if (b0 == guess)
         {
-          PeerBox *pb = a.peers[lane];
-#pragma unroll
-          for (int k = 0; k < 4; k++)
-          {
-            if (v[k] >= PEER_VBIAS || v[k] <= -PEER_VBIAS) failed = 1;     // cannot be encoded: fail loudly
-            __hip_atomic_store(&pb->slot[r % 3][a.rank][k], tag | ((unsigned long long)(v[k] + PEER_VBIAS) & PEER_VMASK),
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-          }
+          if (lane < 4) send_words(r, tsend);
+          sent = true;
         }
-        unsigned long long yy[4] = { 0, 0, 0, 0 };
-        bool got = !other;
-        unsigned spins2 = 0;
-        const PeerBox *pollbox = (a.mirror != NULL && wg != 0) ? a.mirror : a.box;
-        for (;;)
-        {
-          if (!got)
-          {
-#pragma unroll
-            for (int k = 0; k < 4; k++) yy[k] = __hip_atomic_load(&pollbox->slot[r % 3][lane][k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            got = (yy[0] >> 48) == (tag >> 48) && (yy[1] >> 48) == (tag >> 48) && (yy[2] >> 48) == (tag >> 48) && (yy[3] >> 48) == (tag >> 48);
-            if (got && a.mirror != NULL && wg == 0)
-            {
-              // host-memory boxes: only workgroup 0 polls across PCIe; it passes every arriving word on to the local pollers
-#pragma unroll
-              for (int k = 0; k < 4; k++)
-                __hip_atomic_store(&a.mirror->slot[r % 3][lane][k], yy[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-          }
-          if (__all(got)) break;
-          if (++spins2 > PRK_SPIN_LIMIT || ((spins2 & 1023u) == 0 && __hip_atomic_load(errw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0))
-          {
-            failed = 1;
-            break;
-          }
-          __builtin_amdgcn_s_sleep(1);
-        }
-        failed = __any(failed) ? 1 : 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-          v[k] += wave_sum_ll((other && !failed) ? (long long)(yy[k] & PEER_VMASK) - PEER_VBIAS : 0LL);
       }
       CP_TICK(10);               // wave 0: fold (and the cross-device step)
       if (lane == 0)
@@ -705,6 +741,7 @@ __global__ __launch_bounds__((CpCfg<W, K>::MAXT > 0 ? CpCfg<W, K>::MAXT : 64), C
     }
     publish(-1, contrib);
   }
+
   // One column.  The fast and the masked variant are two separate loops below (a wave switches between them when its
   // flanks enter or leave the band's range): with both variants in ONE loop body the register allocator needed ~45
   // registers more than the larger of the two.  Returns true when the column loop ends.
@@ -726,6 +763,218 @@ __global__ __launch_bounds__((CpCfg<W, K>::MAXT > 0 ? CpCfg<W, K>::MAXT : 64), C
     CP_TICK(3);                  // reductions
   };
   auto nothing = []() __attribute__((always_inline)) {};
+  // ---- speculative columns with a vote wave (SYNCW: device-wide mode, blocks of up to 11 cells) --------------------
+  // The vote of row r needs two trips through the memory fabric.  Meanwhile the band waves compute row r against the
+  // WORKGROUP'S OWN argmax of the candidate sums (guess) and carry the speculation through the flank records, the
+  // contributions to row r+1 and their workgroup sums (barrier A).  Wave 0 holds no flank: during the band it waits for the
+  // tickets of row r, folds the shards, applies the stop rule; after A it picks up the workgroup sums, and when the vote
+  // agrees with the guess -- nearly always while the flanks still align -- sends them with the ticket for row r+1 at once.
+  // One word (sm.dec) tells the band waves the winner, the stop rule's verdict and the guess for row r+1 (barrier B).
+  // When the guess was wrong the band waves restore the saved row r-1, run the band again with the true winner, correct
+  // the workgroup sums by the difference (barrier C), and the sums are sent then.  Nothing computed from an unconfirmed
+  // guess ever leaves the workgroup.
+  // dec: bits 0-1 winner, 2 new maximum, 3 stop, 4 failed, 5 guess was wrong, 6-7 guess for the next row
+  int guess_cur = 0;
+  auto argmax4_lds = [&](const unsigned long long *ps) __attribute__((always_inline)) -> int
+  {
+    unsigned long long cbest = 0;
+    int g = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+    {
+      const unsigned long long v = ps[k];
+      const unsigned long long vk = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
+                                    (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+      if (vk > cbest) { cbest = vk; g = k; }
+    }
+    return g;
+  };
+  // wave 0, lanes 0..3 hold t: argmax with the vote's tie rule
+  auto argmax4_lanes = [&](const unsigned long long t) __attribute__((always_inline)) -> int
+  {
+    unsigned long long cbest = 0;
+    int g = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+    {
+      const unsigned long long vk = cp_readlane_u64(t, k);
+      if (vk > cbest) { cbest = vk; g = k; }
+    }
+    return g;
+  };
+  auto sync_column = [&](const int r) __attribute__((always_inline)) -> bool
+  {
+    // ---- the vote of row r: every workgroup's contribution has arrived (bounded spin) ----
+    const unsigned long long *src = vote_src(r);
+    unsigned spins = 0;
+    // workgroup 0: the clearing stores of the previous column (set of row r+2) are complete before this wave sends its
+    // next ticket (see publish)
+    if (wg == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned long long x0 = 0, x1 = 0;
+    bool done = my_shard_blocks <= 0;
+    __builtin_amdgcn_s_sleep(CP_SYNC_FIRST_SLEEP);   // the tickets were sent a moment ago: they need half a microsecond to land
+    for (;;)
+    {
+      if (!done)
+      {
+        typedef unsigned v4u __attribute__((ext_vector_type(4)));
+        v4u q;
+        asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(q) : "v"(src) : "memory");
+        x0 = ((unsigned long long)q.y << 32) | q.x;
+        x1 = ((unsigned long long)q.w << 32) | q.z;
+        done = (x0 >> 54) >= (unsigned long long)my_shard_blocks && (x1 >> 54) >= (unsigned long long)my_shard_blocks;
+      }
+      if (__all(done)) break;
+      if (++spins > PRK_SPIN_LIMIT || ((spins & 1023u) == 0 && __hip_atomic_load(errw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0))
+      {
+        failed = 1;
+        break;
+      }
+    }
+    if (my_shard_blocks <= 0 || failed) { x0 = 0; x1 = 0; }
+    x0 = cp_row_sum_u64(x0); x1 = cp_row_sum_u64(x1);
+    long long v[4];                                              // this GPU's totals
+    {
+      const unsigned long long t0 = cp_readlane_u64(x0, 0) + cp_readlane_u64(x0, 16), t1 = cp_readlane_u64(x1, 0) + cp_readlane_u64(x1, 16);
+      const unsigned long long t2 = cp_readlane_u64(x0, 32) + cp_readlane_u64(x0, 48), t3 = cp_readlane_u64(x1, 32) + cp_readlane_u64(x1, 48);
+      v[0] = (long long)(t0 & (PRK_TICKET - 1)) - (long long)(t0 >> 54) * (long long)PRK_BIAS;
+      v[1] = (long long)(t1 & (PRK_TICKET - 1)) - (long long)(t1 >> 54) * (long long)PRK_BIAS;
+      v[2] = (long long)(t2 & (PRK_TICKET - 1)) - (long long)(t2 >> 54) * (long long)PRK_BIAS;
+      v[3] = (long long)(t3 & (PRK_TICKET - 1)) - (long long)(t3 >> 54) * (long long)PRK_BIAS;
+    }
+    if (a.nranks > 1 && !failed) cross_device(r, v);
+    // ---- winner and stop rule (ram_extend.c:1081-1085, 1194-1216) ----
+    int besta = 0;
+    unsigned chi = 0, clo = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+    {
+      const unsigned hi = (unsigned)((unsigned long long)v[k] >> 32), lo = (unsigned)(unsigned long long)v[k];
+      if (hi != 0 || lo > 2147483647u) ovf = 1;                  // the reference's int accumulator would have wrapped
+      if (hi > chi || (hi == chi && lo > clo)) { chi = hi; clo = lo; besta = k; }
+    }
+    const long long curr = (long long)(((unsigned long long)chi << 32) | clo);
+    int dist = max_row - r;
+    dist = dist < 0 ? -dist : dist;
+    const bool new_max = curr >= max_ext + (long long)dist * a.minimp;
+    if (new_max) { max_row = r; max_ext = curr; }
+    int d2 = r - max_row;
+    d2 = d2 < 0 ? -d2 : d2;
+    stopped = d2 >= a.when_to_stop;
+    rows_done = r + 1;
+    if (wg == 0 && !failed)
+    {
+      if (lane == 0) a.cons_out[(size_t)dd.id * a.L + r] = (signed char)besta;
+      if (lane < NSHARD)            // workgroup 0 clears the device set of row r+3 (see publish)
+      {
+        PShard *z = vote + (size_t)((r + 3) & (RAMX_CP_NSETS - 1)) * NSHARD + lane;
+#pragma unroll
+        for (int k = 0; k < 4; k++) __hip_atomic_store(&z->word[k], 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    const bool wrong = besta != guess_cur;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // A: the workgroup's sums for row r+1 are complete
+    unsigned long long tsend = 0;
+    if (lane < 4)
+    {
+      tsend = sm.vote[(r + 1) & 1][lane];
+      sm.vote[r & 1][lane] = 0ULL;                   // row r's sums: the guess was taken from them a column ago; added to again after B
+    }
+    int gnext = argmax4_lanes(tsend);
+    if (!wrong && !failed && lane < 4) send_words(r, tsend);
+    if (lane == 0)
+    {
+      sm.dec = besta | (new_max ? 4 : 0) | (stopped ? 8 : 0) | (failed ? 16 : 0) | (wrong ? 32 : 0) | (gnext << 6);
+      if (failed) __hip_atomic_store(errw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // B: the decision
+    if (failed) return true;
+    if (wrong)
+    {
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");    // C: corrected sums complete
+      unsigned long long t2 = 0;
+      if (lane < 4) { t2 = sm.vote[(r + 1) & 1][lane]; send_words(r, t2); }
+      gnext = argmax4_lanes(t2);
+    }
+    guess_cur = gnext;
+    return stopped || r == a.L - 1;
+  };
+  auto band_column = [&](const int r, auto gc) __attribute__((always_inline)) -> bool
+  {
+    constexpr bool G = decltype(gc)::value;
+    CP_TICK(7);                  // barrier released .. loop top
+    int bestA[4] = { 0, 0, 0, 0 }, bestF = 0, jb = 0;
+    int sm_[C], se_[C];
+    int high1 = high, pos1 = pos;
+    unsigned contrib[4] = { 0, 0, 0, 0 };
+    if (live)
+    {
+      if (G) set_masks(r);
+      static_for([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value; sm_[i] = m[i]; se_[i] = e[i]; },
+                 std::make_integer_sequence<int, C>{});
+      band(r, guess_cur, gc, bestF, jb, bestA, nothing, nothing);
+      if (bestF > high1) { high1 = bestF; pos1 = r + jb - W; }   // ram_extend.c:1140-1150
+      contributions(bestA, high1, contrib);
+      cp_flank_sum4<K>(contrib);
+      if (lane == 0)
+      {
+#pragma unroll
+        for (int c = 0; c < 4; c++) atomicAdd(&sm.vote[(r + 1) & 1][c], (unsigned long long)contrib[c]);
+      }
+    }
+    CP_TICK(1);                  // speculative band, records, workgroup sums
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // A
+    asm volatile("s_barrier" ::: "memory");                               // B
+    const int dec = __builtin_amdgcn_readfirstlane(sm.dec);
+    CP_TICK(0);                  // waiting for the decision
+    if (dec & 16) { failed = 1; return true; }
+    const int besta = dec & 3;
+    const bool new_max = (dec & 4) != 0, wrong = (dec & 32) != 0;
+    stopped = (dec >> 3) & 1;
+    int gnext = (dec >> 6) & 3;
+    if (live)
+    {
+      if (wrong)
+      {
+        static_for([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value; m[i] = sm_[i]; e[i] = se_[i]; },
+                   std::make_integer_sequence<int, C>{});
+        band(r, besta, gc, bestF, jb, bestA, nothing, nothing);
+        high1 = high; pos1 = pos;
+        if (bestF > high1) { high1 = bestF; pos1 = r + jb - W; }
+        unsigned c2[4];
+        contributions(bestA, high1, c2);
+        cp_flank_sum4<K>(c2);
+        if (lane == 0)
+        {
+          // replace this wave's part of the workgroup sums (64-bit wrap-around: the total stays non-negative)
+#pragma unroll
+          for (int c = 0; c < 4; c++) atomicAdd(&sm.vote[(r + 1) & 1][c], (unsigned long long)c2[c] - (unsigned long long)contrib[c]);
+        }
+#ifdef RAMX_CP_TIMING
+        tsum[6] += 1;            // mispredicted columns
+#endif
+      }
+      high = high1; pos = pos1;
+      if (new_max) { thigh = high; tpos = pos; }                 // :1203-1207
+      slide_window();
+      window_words(AE, AO);      // next column's window
+    }
+    CP_TICK(4);                  // records, window slide, next window
+    if (wrong)
+    {
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");    // C: corrected sums complete
+      gnext = argmax4_lds(sm.vote[(r + 1) & 1]);
+    }
+    guess_cur = gnext;
+    CP_TICK(5);
+    return stopped || r == a.L - 1;
+  };
+  auto column_spec = [&](const int r, auto gc) __attribute__((always_inline)) -> bool
+  {
+    if (wave == 0) return sync_column(r);
+    return band_column(r, gc);
+  };
+  if (SYNCW && a.L > 0) guess_cur = argmax4_lds(sm.vote[0]);     // row 0's workgroup sums (complete since the barrier of column -1)
   auto column = [&](const int r, auto gc) __attribute__((always_inline)) -> bool
   {
     constexpr bool G = decltype(gc)::value;
@@ -733,7 +982,8 @@ __global__ __launch_bounds__((CpCfg<W, K>::MAXT > 0 ? CpCfg<W, K>::MAXT : 64), C
     // fabric; meanwhile the workgroup computes row r against ITS OWN argmax of the candidate sums (the sums it forwarded a
     // moment ago).  When the device-wide vote agrees -- nearly always while the flanks still align -- the row is done when
     // the vote arrives; otherwise the saved row r-1 is restored and the band runs again with the true winner.
-    constexpr bool SPEC = DEV && C <= 11;
+    if constexpr (SYNCW) return column_spec(r, gc);
+    constexpr bool SPEC = false;
     CP_TICK(7);                  // barrier released .. loop top
     int bestA[4] = { 0, 0, 0, 0 }, bestF = 0, jb = 0, guess = -1;
     unsigned long long early0 = 0, early1 = 0, early2 = 0, early3 = 0;
@@ -782,7 +1032,8 @@ __global__ __launch_bounds__((CpCfg<W, K>::MAXT > 0 ? CpCfg<W, K>::MAXT : 64), C
     CP_TICK(1);                  // DEV: speculative band
     if (DEV)
     {
-      wait_vote(r, early0, early1, early2, early3);
+      bool sent_ = false;
+      wait_vote(r, early0, early1, early2, early3, -1, 0ULL, sent_);
       if (__builtin_amdgcn_readfirstlane(sm.fail)) { failed = 1; return true; }
     }
     // vote of row r: block-local (added during the previous column).  The sums are non-negative: they are compared
