@@ -110,27 +110,36 @@ int ramx_cp_launch_families(hipStream_t st, int W, int K, int threads, int F, co
 // ---- device-wide mode ----------------------------------------------------------------------------
 // One workgroup (512 threads unless tuned) per CU at most (the vote barrier wants few participants and the launch must be co-resident).
 // Lanes per flank: as many as keep the set within `cus` workgroups, but not more than a family of that size would get.
-int ramx_cp_device_plan(int W, int n, int cus, int *K, int *threads, int *blocks)
+int ramx_cp_device_plan(int W, int n, int cus, int wide, int *K, int *threads, int *blocks)
 {
   *K = 0; *threads = 0; *blocks = 0;
   if (n <= 0 || cus <= 0) return RAMX_OK;
   const char *fk = getenv("RAMX_CP_K");
   const int force = fk ? atoi(fk) : 0;
+  const char *ft = getenv("RAMX_CP_DEV_THREADS");    // tuning hook: workgroup size of the device-wide launch
+  const int ftv = (ft && atoi(ft) >= 64 && (atoi(ft) & 63) == 0) ? atoi(ft) : 0;
   for (int k = 16; k >= 2; k >>= 1)
   {
     if (force >= 2 && k > force) continue;
-    int t = cp_max_threads(W, cp_cells(W, k));
-    if (t == 0) continue;
-    const char *ft = getenv("RAMX_CP_DEV_THREADS");  // tuning hook: workgroup size of the device-wide launch
-    if (ft && atoi(ft) >= 64 && atoi(ft) <= t && (atoi(ft) & 63) == 0) t = atoi(ft);
-    // short blocks: wave 0 of every workgroup is the vote wave and holds no flank (RAMX_CP_SYNCW_MAXC)
+    const int tmax = cp_max_threads(W, cp_cells(W, k));
+    if (tmax == 0) continue;
+    // short blocks: wave 0 of every workgroup is the vote wave and holds no flank (RAMX_CP_SYNCW_MAXC); four band waves
+    // (one per SIMD) when the set then fits the CUs, eight otherwise (CpCfg::MAXT_DEV)
     const bool syncw = cp_cells(W, k) <= RAMX_CP_SYNCW_MAXC;
-    if (syncw && t < 128) t = 128;
-    const int per = (t - (syncw ? 64 : 0)) / k;
-    const int nb = (n + per - 1) / per;
-    if (nb > cus) continue;
-    *K = k; *threads = t; *blocks = nb;
-    return RAMX_OK;
+    int cand[2], nc = 0;
+    if (ftv) cand[nc++] = ftv < (syncw ? 128 : 64) ? (syncw ? 128 : 64) : (ftv > tmax + (syncw ? 64 : 0) ? tmax + (syncw ? 64 : 0) : ftv);
+    else if (syncw) { if (!wide) cand[nc++] = 320; cand[nc++] = tmax + 64; }
+    else cand[nc++] = tmax;
+    for (int c = 0; c < nc; c++)
+    {
+      const int t = cand[c];
+      const int per = (t - (syncw ? 64 : 0)) / k;
+      if (per <= 0) continue;
+      const int nb = (n + per - 1) / per;
+      if (nb > cus) continue;
+      *K = k; *threads = t; *blocks = nb;
+      return RAMX_OK;
+    }
   }
   return RAMX_OK;
 }
@@ -141,7 +150,7 @@ static int cp_launch_dev(hipStream_t st, int threads, int blocks, const CPArgs &
   if constexpr (CpCfg<W, K>::MAXT == 0) return RAMX_ERR_UNSUPPORTED;
   else
   {
-    if (threads > CpCfg<W, K>::MAXT) return RAMX_ERR_ARG;
+    if (threads > CpCfg<W, K>::MAXT_DEV) return RAMX_ERR_ARG;
     int per_cu = 0, dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return RAMX_ERR_HIP;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ramx_cp_kernel<W, K, true>, threads, 0) != hipSuccess) return RAMX_ERR_HIP;

@@ -58,5 +58,6 @@ int ramx_cp_single_family_max(int W);
 int ramx_cp_launch_families(hipStream_t st, int W, int lanes_per_flank, int threads, int n_families, const CPArgs &a);
 // Device-wide mode: lanes per flank and workgroup count for n flanks on `cus` compute units (one 512-thread workgroup per
 // CU at most), 0 lanes if the set does not fit or the width / scoring system is not supported (ramx_cp_max_family > 0).
-int ramx_cp_device_plan(int W, int n_flanks, int cus, int *lanes_per_flank, int *threads, int *blocks);
+// wide: 0 = four band waves per workgroup when the set then fits `cus` workgroups (lowest latency), 1 = the largest workgroup only
+int ramx_cp_device_plan(int W, int n_flanks, int cus, int wide, int *lanes_per_flank, int *threads, int *blocks);
 int ramx_cp_launch_device(hipStream_t st, int W, int lanes_per_flank, int threads, int blocks, const CPArgs &a);

@@ -751,6 +751,20 @@ extern "C" int ramx_dev_run_families(ramx_dev *d, const ramx_flank *flanks, int3
     if (hipGetDevice(&devo) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, devo) != hipSuccess) cus = 0;
   }
   const bool dev_route = cp_max > 0 && cus > 0 && getenv("RAMX_NO_CP_DEVICE") == NULL && getenv("RAMX_NO_PERSISTENT") == NULL;
+  // small workgroups (four band waves, lowest latency) when all the multi-workgroup families then fit the CUs together
+  int dev_wide = 0;
+  if (dev_route)
+  {
+    long long need = 0;
+    for (int f = 0; f < n_families; f++)
+    {
+      if (fam_count[f] <= cp_max) continue;
+      int k = 0, th = 0, nb = 0;
+      ramx_cp_device_plan(W, fam_count[f], cus, 0, &k, &th, &nb);
+      need += k > 0 ? nb : 0;
+    }
+    dev_wide = need > cus;
+  }
   for (int f = 0; f < n_families; f++)
   {
     int g = RAMX_CP_NCLASS + cls_of(fam_count[f]);
@@ -768,7 +782,7 @@ extern "C" int ramx_dev_run_families(ramx_dev *d, const ramx_flank *flanks, int3
       else if (ok && dev_route)
       {
         int nb = 0;
-        ramx_cp_device_plan(W, fam_count[f], cus, &k, &th, &nb);
+        ramx_cp_device_plan(W, fam_count[f], cus, dev_wide, &k, &th, &nb);
         if (k > 0 && (dev_k == 0 || (k == dev_k && th == dev_threads)) && dev_blocks + nb <= cus)
         {
           dev_k = k; dev_threads = th;
@@ -1071,7 +1085,7 @@ extern "C" int ramx_dev_run_direction(ramx_dev *d, ramx_run_info *info)
     HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     const char *mx = getenv("RAMX_CP_DEVICE_MAXN");
     if (d->cp_flanks_ok && ramx_cp_max_family(a.W, a.go, a.ge, d->tab, L) > 0 && (mx == NULL || d->Nx <= atoi(mx)))
-      ramx_cp_device_plan(a.W, d->Nx > 0 ? d->Nx : 1, cus, &k, &th, &nb);
+      ramx_cp_device_plan(a.W, d->Nx > 0 ? d->Nx : 1, cus, 0, &k, &th, &nb);
     if (multi)
     {
       // my mailbox is cleared BEFORE the agreement, which no remote launch can get past without my taking part

@@ -167,6 +167,8 @@ struct CpCfg
   // because the scan / reduction / vote cost is per wave (tools/cp_cmp_k.sh: 100 flanks at W = 40: 2.58 us per column
   // with 4 lanes per flank, 2.95 with 8).  Blocks of up to 41 cells fit that register budget.
   static constexpr int MAXT = C <= 41 ? 512 : 0;
+  // device-wide mode with a vote wave (RAMX_CP_SYNCW_MAXC): eight band waves and the vote wave
+  static constexpr int MAXT_DEV = C <= RAMX_CP_SYNCW_MAXC ? 576 : MAXT;
 };
 
 // per-lane constants of the cell-parallel band
@@ -356,7 +358,8 @@ __device__ __forceinline__ void cp_reduce(const CpLane &ln, const CpTabs &tabs, 
 #define CP_MIN_WAVES_PER_SIMD 2      // 512 threads, 2 waves per SIMD: 256 VGPRs
 #endif
 template <int W, int K, bool DEV>
-__global__ __launch_bounds__((CpCfg<W, K>::MAXT > 0 ? CpCfg<W, K>::MAXT : 64), CP_MIN_WAVES_PER_SIMD) void ramx_cp_kernel(const CPArgs a)
+__global__ __launch_bounds__((DEV ? (CpCfg<W, K>::MAXT_DEV > 0 ? CpCfg<W, K>::MAXT_DEV : 64) : (CpCfg<W, K>::MAXT > 0 ? CpCfg<W, K>::MAXT : 64)), CP_MIN_WAVES_PER_SIMD)
+void ramx_cp_kernel(const CPArgs a)
 {
   typedef CpCfg<W, K> Cfg;
   constexpr int B = Cfg::B, C = Cfg::C, NA = Cfg::NA, NWL = Cfg::NWL, FPW = 64 / K;
@@ -538,6 +541,17 @@ __global__ __launch_bounds__((CpCfg<W, K>::MAXT > 0 ? CpCfg<W, K>::MAXT : 64), C
   // workgroups that have seen workgroup 0's ticket for row r+2, which wave 0 of workgroup 0 sends at the end of its
   // column r+1 -- after its own wait_vote(r+1), which begins by draining the wave's outstanding stores.  The clear is
   // therefore complete a column before it has to be, and nobody stalls for it.
+  // four wave-uniform values into four LDS words: lanes 0..3 add one word each (one ds_add_u64 for the wave; a single lane
+  // adding four words gets four atomics, each wrapped in the compiler's same-address reduction sequence)
+  auto add4_lds = [&](unsigned long long *dst, const unsigned long long v0, const unsigned long long v1, const unsigned long long v2,
+                      const unsigned long long v3) __attribute__((always_inline))
+  {
+    if (lane < 4)
+    {
+      const unsigned long long mine = lane == 0 ? v0 : lane == 1 ? v1 : lane == 2 ? v2 : v3;
+      atomicAdd(&dst[lane], mine);
+    }
+  };
   // thread k < 4 of the workgroup: word k of the workgroup's sums for row r+1, with the arrival ticket
   auto send_words = [&](int r, unsigned long long t) __attribute__((always_inline))
   {
@@ -549,11 +563,7 @@ __global__ __launch_bounds__((CpCfg<W, K>::MAXT > 0 ? CpCfg<W, K>::MAXT : 64), C
     if (live)
     {
       cp_flank_sum4<K>(contrib);
-      if (lane == 0)
-      {
-#pragma unroll
-        for (int c = 0; c < 4; c++) atomicAdd(&sm.vote[DEV ? ((r + 1) & 1) : (r + 4) % 3][c], (unsigned long long)contrib[c]);
-      }
+      add4_lds(sm.vote[DEV ? ((r + 1) & 1) : (r + 4) % 3], contrib[0], contrib[1], contrib[2], contrib[3]);
     }
     // LDS traffic only: the barrier must not wait for the global accesses in flight (the base word loaded for eight
     // columns ahead, the consensus byte) as __syncthreads() would
@@ -916,11 +926,7 @@ __global__ __launch_bounds__((CpCfg<W, K>::MAXT > 0 ? CpCfg<W, K>::MAXT : 64), C
       if (bestF > high1) { high1 = bestF; pos1 = r + jb - W; }   // ram_extend.c:1140-1150
       contributions(bestA, high1, contrib);
       cp_flank_sum4<K>(contrib);
-      if (lane == 0)
-      {
-#pragma unroll
-        for (int c = 0; c < 4; c++) atomicAdd(&sm.vote[(r + 1) & 1][c], (unsigned long long)contrib[c]);
-      }
+      add4_lds(sm.vote[(r + 1) & 1], contrib[0], contrib[1], contrib[2], contrib[3]);
     }
     CP_TICK(1);                  // speculative band, records, workgroup sums
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // A
@@ -944,12 +950,9 @@ __global__ __launch_bounds__((CpCfg<W, K>::MAXT > 0 ? CpCfg<W, K>::MAXT : 64), C
         unsigned c2[4];
         contributions(bestA, high1, c2);
         cp_flank_sum4<K>(c2);
-        if (lane == 0)
-        {
-          // replace this wave's part of the workgroup sums (64-bit wrap-around: the total stays non-negative)
-#pragma unroll
-          for (int c = 0; c < 4; c++) atomicAdd(&sm.vote[(r + 1) & 1][c], (unsigned long long)c2[c] - (unsigned long long)contrib[c]);
-        }
+        // replace this wave's part of the workgroup sums (64-bit wrap-around: the total stays non-negative)
+        add4_lds(sm.vote[(r + 1) & 1], (unsigned long long)c2[0] - contrib[0], (unsigned long long)c2[1] - contrib[1],
+                 (unsigned long long)c2[2] - contrib[2], (unsigned long long)c2[3] - contrib[3]);
 #ifdef RAMX_CP_TIMING
         tsum[6] += 1;            // mispredicted columns
 #endif
