@@ -40,10 +40,12 @@ int ramx_cp_max_family(int W, int go, int ge, const int (&tab)[RAMX_NCLASS][4], 
 // per CU is the better use of the chip.
 int ramx_cp_single_family_max(int W)
 {
-  int best = 0;
-  for (int K = 16; K >= 2; K >>= 1)
-    if (cp_cells(W, K) <= 21 && cp_max_threads(W, cp_cells(W, K)) / K > best) best = cp_max_threads(W, cp_cells(W, K)) / K;
-  return best;
+  // A family that runs ALONE (seam 1) stays in one workgroup while that keeps sixteen lanes per flank (32 flanks), or eight
+  // for the narrow bands (64 flanks; blocks of 2-3 cells); above that the device-wide mode -- several workgroups of four
+  // band waves and a vote wave -- is faster (profiles/r02_small_route.log: W = 40, 100 flanks: 2.49 -> 1.51 us per column).
+  const char *e = getenv("RAMX_CP_SINGLE_MAX");      // tuning hook
+  if (e && atoi(e) > 0) return atoi(e);
+  return cp_cells(W, 16) >= 5 ? 32 : 64;
 }
 
 // A family takes the most lanes per flank (16, 8, 4, 2) that keep it within one 512-thread workgroup; the classes are

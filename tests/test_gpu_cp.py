@@ -79,7 +79,13 @@ def test_cp_forced_lanes_per_flank(W, K, monkeypatch):
     _check_batch(_families(14, L, W, sizes=(3, 16, 33, 64, 100, 130, 250)), p, min_cp=0)
 
 
-def test_cp_stop_rule_and_degenerate_inputs():
+@pytest.mark.parametrize("route", ["one workgroup", "device-wide"])
+def test_cp_stop_rule_and_degenerate_inputs(route, monkeypatch):
+    """A family of 100 flanks alone runs device-wide (16 lanes per flank, several workgroups); RAMX_CP_SINGLE_MAX keeps it
+    in one workgroup (4 lanes per flank), which is how it runs inside a batch."""
+    if route == "one workgroup":
+        monkeypatch.setenv("RAMX_CP_SINGLE_MAX", "100000")
+    want_lanes = 4 if route == "one workgroup" else 16
     fs = synth_family(100, 90, 14, K=50, seed=17, both_sides=True, minus_frac=0.3)
     for kw in (dict(when_to_stop=0), dict(when_to_stop=1), dict(L=1), dict(L=2, when_to_stop=1), dict(minimprovement=-3),
                dict(cappenalty=0), dict(L=51, when_to_stop=1), dict(L=70, when_to_stop=20), dict(when_to_stop=1000)):
@@ -89,7 +95,7 @@ def test_cp_stop_rule_and_degenerate_inputs():
         a = run_both_directions(oracle_extend, fs.cores, fs.sequence, p)
         b = run_both_directions(gpu_extend, fs.cores, fs.sequence, p)
         assert_same_result(a[0], a[1], a[2:], b[0], b[1], b[2:], str(kw))
-        assert b[2].lanes_per_flank == 4 and b[3].lanes_per_flank == 4
+        assert b[2].lanes_per_flank == want_lanes and b[3].lanes_per_flank == want_lanes
         assert (a[2].rows_executed, a[2].limit_warning, a[3].rows_executed, a[3].limit_warning) == \
                (b[2].rows_executed, b[2].limit_warning, b[3].rows_executed, b[3].limit_warning), str(kw)
     seq = np.array([0, 1, 2, 3] * 40, np.int8)
@@ -105,8 +111,11 @@ def test_cp_stop_rule_and_degenerate_inputs():
 @pytest.mark.parametrize("W,n,K", [(14, 30, 16), (20, 60, 8), (20, 100, 4), (14, 200, 2), (80, 30, 16), (80, 60, 8), (40, 30, 16), (40, 128, 4)])
 def test_cp_state_bit_exact_per_cell(W, n, K, monkeypatch):
     """After L columns the DP row kept by the cell-parallel kernel equals the oracle's row, cell by cell, both states
-    (what bnw_extend.c:1617-1648 asserts for the reference): the scan re-associates the insertion chain exactly."""
+    (what bnw_extend.c:1617-1648 asserts for the reference): the scan re-associates the insertion chain exactly.
+    RAMX_CP_SINGLE_MAX keeps the family in ONE workgroup (every lanes-per-flank shape of the family kernel); alone it
+    would run device-wide above 32 flanks."""
     monkeypatch.setenv("RAMX_CP_PEEK", "1")
+    monkeypatch.setenv("RAMX_CP_SINGLE_MAX", "100000")
     L = 45
     fs = synth_family(n, 70, W, K=40, seed=21 + W, both_sides=True, minus_frac=0.4, n_run_frac=0.2,
                       core_len=(2 * W + 3 if W != 20 else 7))
