@@ -744,8 +744,9 @@ extern "C" int ramx_dev_run_families(ramx_dev *d, const ramx_flank *flanks, int3
   // Families above one cell-parallel workgroup (group -1): several workgroups per family, the family's vote through its
   // own ticket words -- the device-wide mode of the same kernel, all such families in ONE launch of at most one
   // workgroup per CU (every workgroup must be resident).
-  int n_cp = 0, n_dev = 0, dev_blocks = 0, dev_k = 0, dev_threads = 0, cus = 0;
+  int n_cp = 0, n_dev = 0, dev_k = 0, dev_threads = 0, cus = 0;
   std::vector<CpDevDesc> hdev;
+  std::vector<int> dev_round_first, dev_round_blocks;   // rounds of at most `cus` workgroups, launched one after the other
   {
     int devo = 0;
     if (hipGetDevice(&devo) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, devo) != hipSuccess) cus = 0;
@@ -783,9 +784,15 @@ extern "C" int ramx_dev_run_families(ramx_dev *d, const ramx_flank *flanks, int3
       {
         int nb = 0;
         ramx_cp_device_plan(W, fam_count[f], cus, dev_wide, &k, &th, &nb);
-        if (k > 0 && (dev_k == 0 || (k == dev_k && th == dev_threads)) && dev_blocks + nb <= cus)
+        if (k > 0 && nb <= cus && (dev_k == 0 || (k == dev_k && th == dev_threads)))
         {
           dev_k = k; dev_threads = th;
+          if (dev_round_first.empty() || dev_round_blocks.back() + nb > cus)
+          {
+            dev_round_first.push_back((int)hdev.size());
+            dev_round_blocks.push_back(0);
+          }
+          dev_round_blocks.back() += nb;
           for (int b = 0; b < nb; b++)
           {
             CpDevDesc x;
@@ -793,7 +800,6 @@ extern "C" int ramx_dev_run_families(ramx_dev *d, const ramx_flank *flanks, int3
             x.first = fam_first[f]; x.nx = fam_count[f]; x.b = b; x.nb = nb; x.id = f;
             hdev.push_back(x);
           }
-          dev_blocks += nb;
           n_dev++;
           g = -1;
         }
@@ -887,8 +893,12 @@ extern "C" int ramx_dev_run_families(ramx_dev *d, const ramx_flank *flanks, int3
         cp_dbg = ca.dbg;
       }
 #endif
-      rc = ramx_cp_launch_device(st, W, dev_k, dev_threads, dev_blocks, ca);
-      if (rc != RAMX_OK) { ramx_set_error("cell-parallel multi-family device launch failed (W %d, %d workgroups)", W, dev_blocks); goto done; }
+      for (size_t ro = 0; ro < dev_round_first.size(); ro++)
+      {
+        ca.dev = d->d_devdesc + dev_round_first[ro];
+        rc = ramx_cp_launch_device(st, W, dev_k, dev_threads, dev_round_blocks[ro], ca);
+        if (rc != RAMX_OK) { ramx_set_error("cell-parallel multi-family device launch failed (W %d, %d workgroups)", W, dev_round_blocks[ro]); goto done; }
+      }
     }
   }
   // ---- cell-parallel groups ------------------------------------------------------------------
