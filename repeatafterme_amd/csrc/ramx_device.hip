@@ -153,7 +153,7 @@ extern "C" int ramx_dev_create(int ordinal, ramx_dev **out)
   CRCHK(hipHostMalloc((void **)&d->h_ctl, 4 * sizeof(RamxCtl), hipHostMallocDefault));
   CRCHK(hipMalloc((void **)&d->d_sums, (3 * NSHARD * 4 + 8) * sizeof(long long)));
   CRCHK(hipMalloc((void **)&d->d_ctl, 2 * sizeof(RamxCtl)));
-  CRCHK(hipMalloc((void **)&d->d_vote, RAMX_CP_NSETS * NSHARD * sizeof(PShard)));   // 3 sets (persistent kernel) or 4 (cell-parallel)
+  CRCHK(hipMalloc((void **)&d->d_vote, RAMX_CP_NSETS * NSHARD * sizeof(PShard)));   // four rotating sets (both persistent kernels)
   CRCHK(hipMalloc((void **)&d->d_err, 64));
 
   for (int i = 0; i < 2; i++) CRCHK(hipEventCreate(&d->ev_chk[i]));
@@ -636,7 +636,7 @@ static int prk_run(ramx_dev *d, const KArgs &a, int L, bool *used)
   memcpy(pa.tab, a.tab, sizeof(pa.tab));
   pa.pack_ok = getenv("RAMX_NO_FASTPACK") ? 0 : fast_pack_ok(pa.tab, a.go, a.ge, L, W);
   if (pa.pack_ok && getenv("RAMX_NO_MASKHI") == NULL) pa.pack_ok = 2;      // 2: the far-end-masked fast band may be used too
-  HIPCHK(hipMemsetAsync(d->d_vote, 0, 3 * NSHARD * sizeof(PShard), d->stream));
+  HIPCHK(hipMemsetAsync(d->d_vote, 0, RAMX_CP_NSETS * NSHARD * sizeof(PShard), d->stream));
   HIPCHK(hipMemsetAsync(d->d_err, 0, 64, d->stream));
 #ifdef RAMX_PRK_TIMING
   const size_t nw = (size_t)blocks * (block / 64);

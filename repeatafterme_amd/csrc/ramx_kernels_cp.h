@@ -126,26 +126,9 @@ __device__ __forceinline__ unsigned cp_byte_x4(unsigned word)
 // M[T][class]} as four int32, one ds_read_b128 per cell: the candidates' adds are then plain v_add_u32 on two vector
 // registers, which issue at twice the rate of the SDWA byte adds a packed row needs (tools/microbench/valu_rate.hip).
 // Rows of one table sit in different LDS banks, lanes reading the same class broadcast.
-// sum of a 64-bit value over each row of 16 lanes (every lane of the row gets it): xor-1, xor-2 butterflies inside quads,
-// then the mirrored half-row and the mirrored row (sums are uniform below each step, so a mirror reaches the other half)
-__device__ __forceinline__ unsigned long long cp_row_sum_u64(unsigned long long x)
-{
-#define CP_SUM_STEP(ctrl) do { \
-    const unsigned lo_ = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)x, ctrl, 0xf, 0xf, false); \
-    const unsigned hi_ = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(x >> 32), ctrl, 0xf, 0xf, false); \
-    x += ((unsigned long long)hi_ << 32) | lo_; } while (0)
-  CP_SUM_STEP(0xB1);     // quad_perm [1,0,3,2]
-  CP_SUM_STEP(0x4E);     // quad_perm [2,3,0,1]
-  CP_SUM_STEP(0x141);    // row_half_mirror
-  CP_SUM_STEP(0x140);    // row_mirror
-#undef CP_SUM_STEP
-  return x;
-}
-__device__ __forceinline__ unsigned long long cp_readlane_u64(unsigned long long x, int l)
-{
-  return ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(x >> 32), l) << 32) |
-         (unsigned)__builtin_amdgcn_readlane((int)(unsigned)x, l);
-}
+// 64-bit row sums and lane reads of the vote fold: ramx_kernels_resident.h
+#define cp_row_sum_u64 prk_row_sum_u64
+#define cp_readlane_u64 prk_readlane_u64
 
 struct CpTabs
 {

@@ -13,21 +13,49 @@
 // the 32-byte vote.  All L columns run inside one cooperative launch; the dependent-launch boundary of the
 // streaming kernel becomes a device-wide barrier that is fused with the vote:
 //
-//   column c, every block:   4 x int64 atomicAdd into shard (blockIdx % 32) of vote set (c+1) % 3.  Each add
+//   column c, every block:   4 x int64 atomicAdd into shard (blockIdx % 32) of vote set (c+1) % 4.  Each add
 //                            carries its own arrival ticket: value = partial_sum + 2^41 + 2^54, so bits 54..63 of
 //                            a shard word count the blocks that have contributed and the low 54 bits hold
 //                            sum + count * 2^41 (|partial| <= 512 lanes * 2^31 < 2^41: exact for any input).
 //   column c+1, wave 0:      lanes 0..31 poll "their" shard's four words (relaxed agent-scope loads + s_sleep,
 //                            bounded) until all four show every block of the shard, decode, shuffle-reduce and
 //                            publish the vote through LDS.  One fabric round trip after the last arrival.
-//   Set (c+2) % 3 is zeroed by block 0 during column c, before block 0's own adds (everybody finished reading it
-//   before contributing to column c; nobody adds to it before block 0 itself has contributed to column c+1).
+//   Four sets rotate.  Set (c+3) % 4 (last used by row c-1) is zeroed by block 0 during column c, once block 0 has seen
+//   every ticket of row c -- so everybody has finished reading row c-1.  Nobody adds to it before having seen block 0's
+//   ticket for row c+2, which wave 0 of block 0 sends at the end of column c+1, after its own poll for row c+1 -- whose
+//   s_waitcnt vmcnt(0) also drains the zeroing stores of column c (same wave).  The zeroing is complete a column before
+//   it has to be and nobody stalls for it (with three sets block 0 had to wait for its stores before every add).
 //
 // Placement independent: only agent-scope atomics / atomic loads touch shared words, no assumption on which
 // XCD a block runs; co-residency is checked by hipLaunchCooperativeKernel and every spin is bounded (a timeout
 // raises `err` and every block leaves).  Multi-GPU runs keep the per-column launches (RCCL sits between them).
 
-struct PShard { unsigned long long word[4]; unsigned long long pad[4]; };   // 64 B: one cache line per shard
+#ifndef PRK_SHARD_BYTES
+#define PRK_SHARD_BYTES 256   // 64 (one line per shard) measured 1.5-2 % slower: neighbouring shards share a memory channel
+#endif
+struct PShard { unsigned long long word[4]; unsigned long long pad[PRK_SHARD_BYTES / 8 - 4]; };
+
+// sum of a 64-bit value over each row of 16 lanes (every lane of the row gets it): xor-1, xor-2 butterflies inside quads,
+// then the mirrored half-row and the mirrored row (sums are uniform below each step, so a mirror reaches the other half)
+__device__ __forceinline__ unsigned long long prk_row_sum_u64(unsigned long long x)
+{
+#define PRK_SUM_STEP(ctrl) do { \
+    const unsigned lo_ = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)x, ctrl, 0xf, 0xf, false); \
+    const unsigned hi_ = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(x >> 32), ctrl, 0xf, 0xf, false); \
+    x += ((unsigned long long)hi_ << 32) | lo_; } while (0)
+  PRK_SUM_STEP(0xB1);     // quad_perm [1,0,3,2]
+  PRK_SUM_STEP(0x4E);     // quad_perm [2,3,0,1]
+  PRK_SUM_STEP(0x141);    // row_half_mirror
+  PRK_SUM_STEP(0x140);    // row_mirror
+#undef PRK_SUM_STEP
+  return x;
+}
+__device__ __forceinline__ unsigned long long prk_readlane_u64(unsigned long long x, int l)
+{
+  return ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(x >> 32), l) << 32) |
+         (unsigned)__builtin_amdgcn_readlane((int)(unsigned)x, l);
+}
+   // 64 B: one cache line per shard
 #define PRK_BIAS (1ULL << 41)
 #define PRK_TICKET (1ULL << 54)
 
@@ -438,7 +466,7 @@ __global__ __launch_bounds__(BLOCK, 2) void ramx_persistent_kernel(const PArgs a
         // lane = shard + 32 * half polls words 2*half, 2*half+1 of "its" shard: one 16-byte load per lane and round
         // (a quarter of the requests of four 8-byte loads on 32 lanes; the poll competes with the adds it waits for)
         const int sidx = lane & (NSHARD - 1), half = lane >> 5;
-        const unsigned long long *src = &a.vote[(size_t)(r % 3) * NSHARD + sidx].word[2 * half];
+        const unsigned long long *src = &a.vote[(size_t)(r & 3) * NSHARD + sidx].word[2 * half];
         unsigned spins = 0;
         bool done = my_shard_blocks <= 0 || (a.nranks > 1 && blockIdx.x != 0);   // multi-rank: only the exchanger needs the local total
         unsigned long long x0 = 0, x1 = 0;
@@ -461,16 +489,16 @@ __global__ __launch_bounds__(BLOCK, 2) void ramx_persistent_kernel(const PArgs a
           }
           __builtin_amdgcn_s_sleep(1);
         }
-        long long y0 = 0, y1 = 0;
-        if (my_shard_blocks > 0 && !failed && !(a.nranks > 1 && blockIdx.x != 0))
-        {
-          y0 = (long long)(x0 & (PRK_TICKET - 1)) - (long long)(x0 >> 54) * (long long)PRK_BIAS;
-          y1 = (long long)(x1 & (PRK_TICKET - 1)) - (long long)(x1 >> 54) * (long long)PRK_BIAS;
-        }
-        // fold the 32 shards inside each half-wave; lanes 0 / 32 end up with words {0,1} / {2,3}
-#pragma unroll
-        for (int m = 16; m >= 1; m >>= 1) { y0 += __shfl_xor(y0, m, 64); y1 += __shfl_xor(y1, m, 64); }
-        v[0] = __shfl(y0, 0, 64); v[1] = __shfl(y1, 0, 64); v[2] = __shfl(y0, 32, 64); v[3] = __shfl(y1, 32, 64);
+        // fold the 32 shards: the raw words first (sum + bias and ticket fields are both additive: at most 256 tickets,
+        // ten bits), rows of 16 lanes with DPP butterflies, the four rows on the scalar unit; one decode per word
+        if (my_shard_blocks <= 0 || failed || (a.nranks > 1 && blockIdx.x != 0)) { x0 = 0; x1 = 0; }
+        x0 = prk_row_sum_u64(x0); x1 = prk_row_sum_u64(x1);
+        const unsigned long long t0 = prk_readlane_u64(x0, 0) + prk_readlane_u64(x0, 16), t1 = prk_readlane_u64(x1, 0) + prk_readlane_u64(x1, 16);
+        const unsigned long long t2 = prk_readlane_u64(x0, 32) + prk_readlane_u64(x0, 48), t3 = prk_readlane_u64(x1, 32) + prk_readlane_u64(x1, 48);
+        v[0] = (long long)(t0 & (PRK_TICKET - 1)) - (long long)(t0 >> 54) * (long long)PRK_BIAS;
+        v[1] = (long long)(t1 & (PRK_TICKET - 1)) - (long long)(t1 >> 54) * (long long)PRK_BIAS;
+        v[2] = (long long)(t2 & (PRK_TICKET - 1)) - (long long)(t2 >> 54) * (long long)PRK_BIAS;
+        v[3] = (long long)(t3 & (PRK_TICKET - 1)) - (long long)(t3 >> 54) * (long long)PRK_BIAS;
       }
       if (r == 0)
       {
@@ -566,10 +594,10 @@ __global__ __launch_bounds__(BLOCK, 2) void ramx_persistent_kernel(const PArgs a
     stopped = d2 >= a.when_to_stop;
     rows_done = r + 1;
     if (blockIdx.x == 0 && threadIdx.x == 0) a.cons_out[r] = (signed char)besta;
-    // block 0 clears the vote set of row r+2 (see the protocol above)
+    // block 0 clears the vote set of row r+3 (see the protocol above)
     if (blockIdx.x == 0 && threadIdx.x < NSHARD)
     {
-      PShard *z = a.vote + (size_t)((r + 2) % 3) * NSHARD + threadIdx.x;
+      PShard *z = a.vote + (size_t)((r + 3) & 3) * NSHARD + threadIdx.x;
 #pragma unroll
       for (int k = 0; k < 4; k++) __hip_atomic_store(&z->word[k], 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -618,13 +646,12 @@ __global__ __launch_bounds__(BLOCK, 2) void ramx_persistent_kernel(const PArgs a
     }
     __syncthreads();
     PRK_TICK(3);                 // wave reduction + block barrier
-    if (blockIdx.x == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // block 0: its zeroing stores first
     if (threadIdx.x < 4)
     {
       long long t = 0;
 #pragma unroll
       for (int wv = 0; wv < WPB; wv++) t += s_red[wv][threadIdx.x];
-      PShard *sh = a.vote + (size_t)((r + 1) % 3) * NSHARD + shard;
+      PShard *sh = a.vote + (size_t)((r + 1) & 3) * NSHARD + shard;
       __hip_atomic_fetch_add(&sh->word[threadIdx.x], (unsigned long long)t + PRK_BIAS + PRK_TICKET, __ATOMIC_RELAXED,
                              __HIP_MEMORY_SCOPE_AGENT);
     }
