@@ -260,12 +260,10 @@ __device__ __forceinline__ void cp_update(const CpLane &ln, const int go, const 
 
 // Best cell of row r (value, lowest cell on ties: bnw_extend.c:1020-1024) and the best cells of the four candidate rows
 // r+1 (chain-free rule of ramx_kernels_common.h), reduced over the group: every lane returns the same values.
-struct CpNoHook { __device__ __forceinline__ void operator()() const {} };
-template <int W, int K, bool G, class Hook = CpNoHook>
+template <int W, int K, bool G>
 __device__ __forceinline__ void cp_reduce(const CpLane &ln, const CpTabs &tabs, const unsigned (&AE)[CpCfg<W, K>::NA],
                                           const unsigned (&AO)[CpCfg<W, K>::NA], const int (&m)[CpCfg<W, K>::C],
-                                          const int (&e)[CpCfg<W, K>::C], int &bestF, int &jbest, int (&bestA)[4],
-                                          Hook &&before_allmax = CpNoHook())
+                                          const int (&e)[CpCfg<W, K>::C], int &bestF, int &jbest, int (&bestA)[4])
 {
   typedef CpCfg<W, K> Cfg;
   constexpr int C = Cfg::C, IB = Cfg::IB;
@@ -309,7 +307,6 @@ __device__ __forceinline__ void cp_reduce(const CpLane &ln, const CpTabs &tabs, 
   if (!G) kb = ln.pDead ? CP_IMIN : kb;
   kb += ln.keyfix;                                               // low byte: 255 - j of the block's best cell
   int r0 = imax(bA[0], mE), r1 = imax(bA[1], mE), r2 = imax(bA[2], mE), r3 = imax(bA[3], mE);
-  before_allmax();
   cp_allmax5<K>(r0, r1, r2, r3, kb);
   bestA[0] = r0; bestA[1] = r1; bestA[2] = r2; bestA[3] = r3;
   bestF = kb >> 8;
@@ -326,9 +323,6 @@ __device__ __forceinline__ void cp_reduce(const CpLane &ln, const CpTabs &tabs, 
 // ------------------------------------------------------------------------------------------
 #ifndef CP_SYNC_FIRST_SLEEP
 #define CP_SYNC_FIRST_SLEEP 4   // s_sleep units (64 clocks) before the vote wave's first look at the tickets of a row
-#endif
-#ifndef CP_LATE_POLL
-#define CP_LATE_POLL 1     // second poll of the ticket words during the speculative band (0: A/B builds)
 #endif
 #ifdef RAMX_CP_TIMING
 #define CP_TICK(k) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
@@ -622,10 +616,8 @@ void ramx_cp_kernel(const CPArgs a)
       for (int k = 0; k < 4; k++)
         v[k] += wave_sum_ll((other && !failed) ? (long long)(yy[k] & PEER_VMASK) - PEER_VBIAS : 0LL);
   };
-  // guess / tsend / sent (speculative columns): when the vote confirms the workgroup's guess, lanes 0..3 of wave 0 send the
-  // workgroup's sums for row r+1 (tsend, built from the speculative row) and the ticket at once -- before anything else
-  auto wait_vote = [&](int r, unsigned long long e0, unsigned long long e1, unsigned long long e2, unsigned long long e3,
-                       const int guess, const unsigned long long tsend, bool &sent) __attribute__((always_inline))
+  // (blocks of more than RAMX_CP_SYNCW_MAXC cells: the simple order -- vote, then band; no vote wave)
+  auto wait_vote = [&](int r) __attribute__((always_inline))
   {
     if (wave == 0)
     {
@@ -635,19 +627,11 @@ void ramx_cp_kernel(const CPArgs a)
       // its next ticket (see publish)
       if (wg == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       CP_TICK(8);                // wave 0: drain
-      // (e0, e1), (e2, e3): polls issued during the speculative band (0 when there was none); the later one is usually
-      // complete.  Tickets only grow within a row, so whichever sample is complete holds the final sums.
-      unsigned long long x0 = e0, x1 = e1;
+      unsigned long long x0 = 0, x1 = 0;
 #ifdef CP_PROBE_NO_WAIT          // timing probe only (wrong results): whatever has arrived is the vote
       bool done = true;
 #else
-      bool done = my_shard_blocks <= 0 ||
-                  ((x0 >> 54) >= (unsigned long long)my_shard_blocks && (x1 >> 54) >= (unsigned long long)my_shard_blocks);
-      if (!done)
-      {
-        x0 = e2; x1 = e3;
-        done = (x0 >> 54) >= (unsigned long long)my_shard_blocks && (x1 >> 54) >= (unsigned long long)my_shard_blocks;
-      }
+      bool done = my_shard_blocks <= 0;
 #endif
       for (;;)
       {
@@ -684,18 +668,6 @@ void ramx_cp_kernel(const CPArgs a)
         v[3] = (long long)(t3 & (PRK_TICKET - 1)) - (long long)(t3 >> 54) * (long long)PRK_BIAS;
       }
       if (a.nranks > 1 && !failed) cross_device(r, v);
-      if (guess >= 0 && !failed)
-      {
-        int b0 = 0;
-        unsigned long long c0 = 0;     // the rule of the vote read in the column (unsigned, first maximum wins)
-#pragma unroll
-        for (int k = 0; k < 4; k++) if ((unsigned long long)v[k] > c0) { c0 = (unsigned long long)v[k]; b0 = k; }
-        if (b0 == guess)
-        {
-          if (lane < 4) send_words(r, tsend);
-          sent = true;
-        }
-      }
       CP_TICK(10);               // wave 0: fold (and the cross-device step)
       if (lane == 0)
       {
@@ -739,11 +711,10 @@ void ramx_cp_kernel(const CPArgs a)
   // flanks enter or leave the band's range): with both variants in ONE loop body the register allocator needed ~45
   // registers more than the larger of the two.  Returns true when the column loop ends.
   // the band of one row against winner b: row r from row r-1, best cell of row r, best cells of the candidate rows r+1
-  auto band = [&](const int r, const int b, auto gc, int &bestF, int &jb, int (&bestA)[4], auto &&between, auto &&late) __attribute__((always_inline))
+  auto band = [&](const int r, const int b, auto gc, int &bestF, int &jb, int (&bestA)[4]) __attribute__((always_inline))
   {
     constexpr bool G = decltype(gc)::value;
 #ifdef CP_PROBE_NO_BAND          // timing probe only (wrong results): the column without its arithmetic
-    between();
     bestF = r; jb = W;
     return;
 #endif
@@ -751,11 +722,9 @@ void ramx_cp_kernel(const CPArgs a)
     winner_scores(AE, AO, b, sFv);
     cp_update<W, K, G>(ln, vgo, vge, a.go + (r + 1) * a.ge /* edge fill, first W rows only (set_masks: iWr) */, sFv, m, e);
     CP_TICK(2);                  // row update
-    between();
-    cp_reduce<W, K, G>(ln, sm.tabs, AE, AO, m, e, bestF, jb, bestA, late);
+    cp_reduce<W, K, G>(ln, sm.tabs, AE, AO, m, e, bestF, jb, bestA);
     CP_TICK(3);                  // reductions
   };
-  auto nothing = []() __attribute__((always_inline)) {};
   // ---- speculative columns with a vote wave (SYNCW: device-wide mode, blocks of up to 11 cells) --------------------
   // The vote of row r needs two trips through the memory fabric.  Meanwhile the band waves compute row r against the
   // WORKGROUP'S OWN argmax of the candidate sums (guess) and carry the speculation through the flank records, the
@@ -905,7 +874,7 @@ void ramx_cp_kernel(const CPArgs a)
       if (G) set_masks(r);
       static_for([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value; sm_[i] = m[i]; se_[i] = e[i]; },
                  std::make_integer_sequence<int, C>{});
-      band(r, guess_cur, gc, bestF, jb, bestA, nothing, nothing);
+      band(r, guess_cur, gc, bestF, jb, bestA);
       if (bestF > high1) { high1 = bestF; pos1 = r + jb - W; }   // ram_extend.c:1140-1150
       contributions(bestA, high1, contrib);
       cp_flank_sum4<K>(contrib);
@@ -927,7 +896,7 @@ void ramx_cp_kernel(const CPArgs a)
       {
         static_for([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value; m[i] = sm_[i]; e[i] = se_[i]; },
                    std::make_integer_sequence<int, C>{});
-        band(r, besta, gc, bestF, jb, bestA, nothing, nothing);
+        band(r, besta, gc, bestF, jb, bestA);
         high1 = high; pos1 = pos;
         if (bestF > high1) { high1 = bestF; pos1 = r + jb - W; }
         unsigned c2[4];
@@ -964,62 +933,13 @@ void ramx_cp_kernel(const CPArgs a)
   auto column = [&](const int r, auto gc) __attribute__((always_inline)) -> bool
   {
     constexpr bool G = decltype(gc)::value;
-    // Speculation (device-wide mode, blocks of up to 11 cells): the vote of row r needs two trips through the memory
-    // fabric; meanwhile the workgroup computes row r against ITS OWN argmax of the candidate sums (the sums it forwarded a
-    // moment ago).  When the device-wide vote agrees -- nearly always while the flanks still align -- the row is done when
-    // the vote arrives; otherwise the saved row r-1 is restored and the band runs again with the true winner.
     if constexpr (SYNCW) return column_spec(r, gc);
-    constexpr bool SPEC = false;
     CP_TICK(7);                  // barrier released .. loop top
-    int bestA[4] = { 0, 0, 0, 0 }, bestF = 0, jb = 0, guess = -1;
-    unsigned long long early0 = 0, early1 = 0, early2 = 0, early3 = 0;
-    int sm_[SPEC ? C : 1], se_[SPEC ? C : 1];
+    int bestA[4] = { 0, 0, 0, 0 }, bestF = 0, jb = 0;
     if (G && live) set_masks(r);
-    if constexpr (SPEC)
-    {
-      // prediction: argmax of this workgroup's partial sums for row r, same tie rule as the vote
-      const unsigned long long *ps = sm.vote[r & 1];
-      unsigned long long cbest = 0;
-      guess = 0;
-#pragma unroll
-      for (int k = 0; k < 4; k++)
-      {
-        const unsigned long long v = ps[k];
-        const unsigned long long vk = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
-                                      (unsigned)__builtin_amdgcn_readfirstlane((int)v);
-        if (vk > cbest) { cbest = vk; guess = k; }
-      }
-      if (live)
-      {
-        static_for([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value; sm_[i] = m[i]; se_[i] = e[i]; },
-                   std::make_integer_sequence<int, C>{});
-        // wave 0 looks at the ticket words twice during the band (after the row update and before the wave-wide
-        // reductions): the loads travel while the band runs.  The other workgroups' adds were issued at the end of the
-        // previous column and land about half a band later; a poll sent just after that returns as the band ends.
-        band(r, guess, gc, bestF, jb, bestA, [&]() __attribute__((always_inline))
-        {
-          if (wave == 0 && my_shard_blocks > 0)
-          {
-            const unsigned long long *src = vote_src(r);
-            early0 = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            early1 = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
-        }, [&]() __attribute__((always_inline))
-        {
-          if (CP_LATE_POLL && wave == 0 && my_shard_blocks > 0)
-          {
-            const unsigned long long *src = vote_src(r);
-            early2 = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            early3 = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
-        });
-      }
-    }
-    CP_TICK(1);                  // DEV: speculative band
     if (DEV)
     {
-      bool sent_ = false;
-      wait_vote(r, early0, early1, early2, early3, -1, 0ULL, sent_);
+      wait_vote(r);
       if (__builtin_amdgcn_readfirstlane(sm.fail)) { failed = 1; return true; }
     }
     // vote of row r: block-local (added during the previous column).  The sums are non-negative: they are compared
@@ -1063,16 +983,7 @@ void ramx_cp_kernel(const CPArgs a)
     CP_TICK(0);                  // vote read, stop rule
     if (live)
     {
-      if constexpr (!SPEC) band(r, besta, gc, bestF, jb, bestA, nothing, nothing);
-      else if (guess != besta)
-      {
-        static_for([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value; m[i] = sm_[i]; e[i] = se_[i]; },
-                   std::make_integer_sequence<int, C>{});
-        band(r, besta, gc, bestF, jb, bestA, nothing, nothing);
-#ifdef RAMX_CP_TIMING
-        tsum[6] += 1;            // mispredicted columns
-#endif
-      }
+      band(r, besta, gc, bestF, jb, bestA);
       if (bestF > high) { high = bestF; pos = r + jb - W; }      // ram_extend.c:1140-1150
       if (new_max) { thigh = high; tpos = pos; }                 // :1203-1207
       finish_column(bestA, contrib);
