@@ -46,6 +46,7 @@ struct CPArgs
   struct PeerBox *box;          // this rank's own box
   struct PeerBox *mirror;       // host-memory boxes only: device copy kept current by workgroup 0 (NULL: everybody polls `box`)
   int rank, nranks;
+  int test_drop_row;   // test hook (RAMX_TEST_CP_DROP_TICKET=row): the last workgroup of every set withholds its words for that row; 0 = off
 };
 
 #define RAMX_CP_NCLASS 6

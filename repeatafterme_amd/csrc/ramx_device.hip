@@ -1138,6 +1138,7 @@ extern "C" int ramx_dev_run_direction(ramx_dev *d, ramx_run_info *info)
           HIPCHK(hipStreamSynchronize(d->stream));       // hd goes out of scope
         }
         ca.dev = d->d_devdesc; ca.vote = d->d_vote; ca.err = d->d_err; ca.S = d->d_state[0];
+        { const char *td = getenv("RAMX_TEST_CP_DROP_TICKET"); ca.test_drop_row = td ? atoi(td) : 0; }
         ca.nranks = 1; ca.rank = 0;
         if (multi)
         {

@@ -532,6 +532,7 @@ void ramx_cp_kernel(const CPArgs a)
   // thread k < 4 of the workgroup: word k of the workgroup's sums for row r+1, with the arrival ticket
   auto send_words = [&](int r, unsigned long long t) __attribute__((always_inline))
   {
+    if (a.test_drop_row > 0 && r + 1 == a.test_drop_row && wg == dd.nb - 1) return;   // test hook: every workgroup then times out
     PShard *sh = vote + (size_t)((r + 1) & (RAMX_CP_NSETS - 1)) * NSHARD + (wg % NSHARD);
     __hip_atomic_fetch_add(&sh->word[threadIdx.x], t + PRK_BIAS + PRK_TICKET, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };

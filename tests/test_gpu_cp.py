@@ -193,6 +193,22 @@ def test_cp_device_wide_equals_oracle(W, n, K, matrix):
     assert b[2].persistent == 1 and b[2].lanes_per_flank == K and b[3].lanes_per_flank == K
 
 
+@pytest.mark.parametrize("W,n", [(40, 700), (40, 20000)])
+def test_cp_device_wide_lost_ticket_times_out_and_falls_back(W, n, monkeypatch):
+    """One workgroup withholds its words for row 7 (test hook): every vote wave runs into its bounded spin, raises the
+    error word, every workgroup leaves, and the host repeats the direction on the lane-per-flank route -- same results,
+    no hang.  n = 700: vote-wave kernel (blocks of 6 cells); n = 20,000: the simple order (21 cells per lane)."""
+    monkeypatch.setenv("RAMX_TEST_CP_DROP_TICKET", "7")
+    L = 60
+    fs = synth_family(n, L, W, K=40, seed=77, both_sides=True, minus_frac=0.3, n_run_frac=0.1)
+    p = po.Params.named("14p43g", bandwidth=W, L=L, when_to_stop=20)
+    a = run_both_directions(oracle_extend, fs.cores, fs.sequence, p)
+    b = run_both_directions(gpu_extend, fs.cores, fs.sequence, p)
+    assert_same_result(a[0], a[1], a[2:], b[0], b[1], b[2:], f"W={W} n={n}")
+    assert (a[2].rows_executed, a[3].rows_executed) == (b[2].rows_executed, b[3].rows_executed)
+    assert b[2].lanes_per_flank == 1 and b[3].lanes_per_flank == 1      # the cell-parallel launch gave up
+
+
 @pytest.mark.parametrize("K", [2, 4, 8, 16])
 def test_cp_device_wide_small_sets_every_shape(K, monkeypatch):
     """With the one-workgroup route off even a tiny set runs device-wide: adversarial ragged sets (masked path, flanks
