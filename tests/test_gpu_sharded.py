@@ -131,6 +131,29 @@ def test_two_ranks_cross_device_persistent_path(W, kind, no_cp):
         assert np.array_equal(sc, c.score)
 
 
+@pytest.mark.parametrize("K", [4, 2])
+def test_two_ranks_cell_parallel_long_blocks(K, monkeypatch):
+    """RAMX_CP_K caps the lanes per flank: 21 and 41 cells per lane at W = 40 -- the device-wide kernel WITHOUT a vote wave
+    (vote, then band), which is what 25,000-50,000 flanks per rank get.  Same exchange through the mailboxes."""
+    from oracle import pyoracle as po
+    from repeatafterme_amd.datamodel import new_master
+    from repeatafterme_amd.synth import synth_family
+    monkeypatch.setenv("RAMX_CP_K", str(K))             # inherited by the spawned ranks
+    world = 2
+    out = mp.Manager().dict()
+    mp.spawn(_worker, args=(world, _free_port(), out, True, 40, "device", None, False), nprocs=world, join=True)
+    fs = synth_family(333, 150, 40, K=100, seed=12, both_sides=True, minus_frac=0.3, n_run_frac=0.1)
+    p = po.Params.named("14p43g", bandwidth=40, L=150, when_to_stop=25)
+    c = fs.cores.copy(); m = new_master(p.L)
+    r1 = po.oracle_extend(1, c, fs.sequence, m, p); r0 = po.oracle_extend(0, c, fs.sequence, m, p)
+    for rank in range(world):
+        rets, mm, ll, rl, sc, enabled, used, lanes = out[rank]
+        assert enabled and used == 1 and lanes == K, (enabled, used, lanes)
+        assert rets == [(r1.ret, r1.rows_executed), (r0.ret, r0.rows_executed)], rank
+        assert np.array_equal(mm, m) and np.array_equal(ll, c.left_len) and np.array_equal(rl, c.right_len)
+        assert np.array_equal(sc, c.score), np.flatnonzero(sc != c.score)[:10]
+
+
 @pytest.mark.parametrize("no_cp", [False, True], ids=["cell-parallel", "lane-per-flank"])
 @pytest.mark.parametrize("late", [0, 1])
 def test_two_ranks_one_launches_late(late, no_cp):
