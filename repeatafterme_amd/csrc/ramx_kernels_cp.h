@@ -190,12 +190,22 @@ __device__ __forceinline__ int cp_fill(int iWr, int edge)      // (I < iWr) ? ed
 }
 
 // Row r from row r-1 (bnw_extend.c:750-1048), cells split over the group.  G: masked (general) path.
-template <int W, int K, bool G>
+// sf(ic): the winner's substitution score of cell i (an LDS lookup).  The scores are fetched CP_SF_AHEAD cells ahead of
+// their use: blocks of up to 21 cells fetch everything up front (lowest latency), blocks of 41 cells keep twelve in flight
+// instead of a register per cell (device-wide W = 40, K = 2: 225 spilled registers -> 74).
+#ifndef CP_SF_AHEAD
+#define CP_SF_AHEAD 12
+#endif
+template <int W, int K, bool G, class SF>
 __device__ __forceinline__ void cp_update(const CpLane &ln, const int go, const int ge, const int edgeFx,
-                                          const int (&sFv)[CpCfg<W, K>::C], int (&m)[CpCfg<W, K>::C], int (&e)[CpCfg<W, K>::C])
+                                          SF &&sf, int (&m)[CpCfg<W, K>::C], int (&e)[CpCfg<W, K>::C])
 {
   typedef CpCfg<W, K> Cfg;
   constexpr int C = Cfg::C, IB = Cfg::IB;
+  constexpr int QA = C <= 21 ? C : CP_SF_AHEAD;       // measured: a queue costs blocks of 21 cells 8 %, saves blocks of 41 cells 5 %
+  int sq[QA];
+  static_for([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value; sq[i] = sf(ic); },
+             std::make_integer_sequence<int, QA>{});
   if (G)
   {
     // The masked and the fast variant start with the same arithmetic on every cell (score lookup, substitution term);
@@ -221,7 +231,8 @@ __device__ __forceinline__ void cp_update(const CpLane &ln, const int go, const 
     constexpr int i = decltype(ic)::value;
     // masked path: keep the scheduler from hoisting every cell's fills and range tests to the top of the block
     if constexpr ((i % (G ? CP_G_GROUP : CP_F_GROUP)) == 0) __builtin_amdgcn_sched_barrier(0);
-    const int sub = m[i] + sFv[i];                               // :950-956, sFv[i] = M[besta][base of cell i]
+    const int sub = m[i] + sq[i % QA];                           // :950-956, M[besta][base of cell i]
+    if constexpr (i + QA < C) sq[i % QA] = sf(std::integral_constant<int, (i + QA < C ? i + QA : 0)>{});
     int del = peNext;                                            // :892-905
     if constexpr (i + 1 < C) del = e[i + 1];
     if constexpr (i == IB) del = ln.pPart ? NEG : del;           // cell 2W has no deletion predecessor
@@ -444,23 +455,6 @@ void ramx_cp_kernel(const CPArgs a)
     }, std::make_integer_sequence<int, NA>{});
   };
   // substitution scores of row r's cells against the winner `besta`: win[besta][class]
-  auto winner_scores = [&](const unsigned (&AE)[NA], const unsigned (&AO)[NA], const int besta, int (&sFv)[C]) __attribute__((always_inline))
-  {
-    const unsigned bb = 0x40404040u * (unsigned)besta;           // + 64 * besta in every byte (4 * class <= 60)
-    unsigned WE[NA], WO[NA];
-    static_for([&](auto kc) __attribute__((always_inline))
-    {
-      constexpr int k = decltype(kc)::value;
-      WE[k] = AE[k] | bb; WO[k] = AO[k] | bb;
-    }, std::make_integer_sequence<int, NA>{});
-    const char *tw = reinterpret_cast<const char *>(&sm.tabs.win[0][0]);
-    static_for([&](auto ic) __attribute__((always_inline))
-    {
-      constexpr int i = decltype(ic)::value;
-      const unsigned off = cp_byte<((i & 7) >> 1)>((i & 1) ? WO[i >> 3] : WE[i >> 3]);
-      sFv[i] = *reinterpret_cast<const int *>(tw + off);
-    }, std::make_integer_sequence<int, C>{});
-  };
   auto set_masks = [&](int r) __attribute__((always_inline))
   {
     const int jlo = bd.x - r, jhi = bd.y - r;        // cell j of row r is in bounds iff jlo <= j <= jhi
@@ -719,9 +713,16 @@ void ramx_cp_kernel(const CPArgs a)
     bestF = r; jb = W;
     return;
 #endif
-    int sFv[C];
-    winner_scores(AE, AO, b, sFv);
-    cp_update<W, K, G>(ln, vgo, vge, a.go + (r + 1) * a.ge /* edge fill, first W rows only (set_masks: iWr) */, sFv, m, e);
+    // the winner's score of cell i: table win[b][class of the cell's base], byte offset 64 * b + 4 * class
+    const unsigned bb = 0x40404040u * (unsigned)b;
+    const char *tw = reinterpret_cast<const char *>(&sm.tabs.win[0][0]);
+    auto sf = [&](auto ic) __attribute__((always_inline)) -> int
+    {
+      constexpr int i = decltype(ic)::value;
+      const unsigned off = cp_byte<((i & 7) >> 1)>(((i & 1) ? AO[i >> 3] : AE[i >> 3]) | bb);
+      return *reinterpret_cast<const int *>(tw + off);
+    };
+    cp_update<W, K, G>(ln, vgo, vge, a.go + (r + 1) * a.ge /* edge fill, first W rows only (set_masks: iWr) */, sf, m, e);
     CP_TICK(2);                  // row update
     cp_reduce<W, K, G>(ln, sm.tabs, AE, AO, m, e, bestF, jb, bestA);
     CP_TICK(3);                  // reductions
