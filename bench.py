@@ -307,6 +307,24 @@ def main():
                  "ms_right": t_r * 1e3, "ms_left": t_l * 1e3, "columns": s_cols, "columns_per_sec": s_cols / (t_r + t_l),
                  "flank_bp_per_sec": (r_right.rows_executed * r_right.n_extendable + r_left.rows_executed * r_left.n_extendable) / (t_r + t_l),
                  "loop_ms_right": r_right.loop_ms, "prep_ms_right": r_right.prep_ms}
+    # ---- outside the timed region: BASELINE configs[1] (N = 1,000 x L = 2,000: a parity configuration, not the bench
+    # line) through seam 1 -- the size class where a column is a latency chain, served by the cell-parallel kernel ------
+    cfg1 = None
+    if world == 1 and not args.no_seam1 and args.flanks == 100000 and W == 40:
+        from repeatafterme_amd.datamodel import new_master
+        from repeatafterme_amd.extend import extend_alignment
+        f1 = synth_family(1000, 2000, W, K=1500, seed=3)
+        p1 = ExtendParams(bandwidth=W, cappenalty=p.cappenalty, minimprovement=p.minimprovement, L=2000, when_to_stop=2000, l=1,
+                          gapopen=go, gapextn=ge, matrix=mat, matrix_name="14p43g")
+        best = None
+        for _ in range(3):
+            c1 = f1.cores.copy(); m1 = new_master(2000)
+            r1 = extend_alignment(1, c1, f1.sequence, m1, p1)
+            us = 1e3 * r1.loop_ms / max(r1.rows_executed, 1)
+            best = us if best is None else min(best, us)
+        cfg1 = {"workload": "synthetic N=1000 flanks x L=2000 bp, bandwidth=40, right extension, all L columns (BASELINE configs[1])",
+                "us_per_column": best, "columns": r1.rows_executed, "lanes_per_flank": r1.lanes_per_flank, "one_launch": bool(r1.persistent),
+                "flank_bp_per_sec": 1000 * 1e6 / best if best else None}
     out = {
         "metric": "flank_bp_aligned_per_sec (extension columns/s x flanks)", "value": value, "unit": "flank-bp/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -326,6 +344,7 @@ def main():
         "cell_updates_per_sec": cols / dt * total_flanks * (2 * W + 1) * 4,
         "roofline": roof,
         "seam1": seam1,
+        "configs1_n1000": cfg1,
         "setup": {"synth_s": t_gen, "upload_pack_s": t_upload},
     }
     if rank == 0 and world == 1 and not args.no_cpu:
