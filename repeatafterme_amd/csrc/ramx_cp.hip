@@ -112,34 +112,48 @@ int ramx_cp_launch_families(hipStream_t st, int W, int K, int threads, int F, co
 // ---- device-wide mode ----------------------------------------------------------------------------
 // One workgroup (512 threads unless tuned) per CU at most (the vote barrier wants few participants and the launch must be co-resident).
 // Lanes per flank: as many as keep the set within `cus` workgroups, but not more than a family of that size would get.
-int ramx_cp_device_plan(int W, int n, int cus, int wide, int *K, int *threads, int *blocks)
+int ramx_cp_device_plan(int W, int n, int cus, int wide, int *K, int *threads, int *blocks, int *vote_wave)
 {
-  *K = 0; *threads = 0; *blocks = 0;
+  *K = 0; *threads = 0; *blocks = 0; *vote_wave = 0;
   if (n <= 0 || cus <= 0) return RAMX_OK;
   const char *fk = getenv("RAMX_CP_K");
   const int force = fk ? atoi(fk) : 0;
   const char *ft = getenv("RAMX_CP_DEV_THREADS");    // tuning hook: workgroup size of the device-wide launch
   const int ftv = (ft && atoi(ft) >= 64 && (atoi(ft) & 63) == 0) ? atoi(ft) : 0;
+  const bool no_vw = getenv("RAMX_CP_NO_VOTE_WAVE") != NULL;   // A/B hook (blocks of 12..21 cells only: shorter blocks have no other mode)
   for (int k = 16; k >= 2; k >>= 1)
   {
     if (force >= 2 && k > force) continue;
-    const int tmax = cp_max_threads(W, cp_cells(W, k));
+    const int cells = cp_cells(W, k);
+    const int tmax = cp_max_threads(W, cells);
     if (tmax == 0) continue;
-    // short blocks: wave 0 of every workgroup is the vote wave and holds no flank (RAMX_CP_SYNCW_MAXC); four band waves
-    // (one per SIMD) when the set then fits the CUs, eight otherwise (CpCfg::MAXT_DEV)
-    const bool syncw = cp_cells(W, k) <= RAMX_CP_SYNCW_MAXC;
-    int cand[2], nc = 0;
-    if (ftv) cand[nc++] = ftv < (syncw ? 128 : 64) ? (syncw ? 128 : 64) : (ftv > tmax + (syncw ? 64 : 0) ? tmax + (syncw ? 64 : 0) : ftv);
-    else if (syncw) { if (!wide) cand[nc++] = 320; cand[nc++] = tmax + 64; }
-    else cand[nc++] = tmax;
+    // Blocks of up to RAMX_CP_SYNCW_MAXC cells: wave 0 of every workgroup is the vote wave and holds no flank.  Four band
+    // waves (one per SIMD) when the set then fits the CUs; else the largest workgroup: eight band waves while the saved
+    // row lives in registers, seven when it lives in LDS -- and for those, before giving up lanes per flank, the plain
+    // order without a vote wave (eight band waves again).
+    const bool syncw = cells <= RAMX_CP_SYNCW_MAXC, regs = cells <= RAMX_CP_SYNCW_REGC;
+    int cand_t[3], cand_vw[3], nc = 0;
+    if (ftv)
+    {
+      const int vw = syncw && (regs || !no_vw);
+      const int tbig = vw ? (regs ? tmax + 64 : tmax) : tmax;
+      cand_t[nc] = ftv < (vw ? 128 : 64) ? (vw ? 128 : 64) : (ftv > tbig ? tbig : ftv); cand_vw[nc++] = vw;
+    }
+    else if (syncw && regs) { if (!wide) { cand_t[nc] = 320; cand_vw[nc++] = 1; } cand_t[nc] = tmax + 64; cand_vw[nc++] = 1; }
+    else if (syncw)
+    {
+      if (!no_vw) { if (!wide) { cand_t[nc] = 320; cand_vw[nc++] = 1; } cand_t[nc] = tmax; cand_vw[nc++] = 1; }
+      cand_t[nc] = tmax; cand_vw[nc++] = 0;
+    }
+    else { cand_t[nc] = tmax; cand_vw[nc++] = 0; }
     for (int c = 0; c < nc; c++)
     {
-      const int t = cand[c];
-      const int per = (t - (syncw ? 64 : 0)) / k;
+      const int t = cand_t[c];
+      const int per = (t - (cand_vw[c] ? 64 : 0)) / k;
       if (per <= 0) continue;
       const int nb = (n + per - 1) / per;
       if (nb > cus) continue;
-      *K = k; *threads = t; *blocks = nb;
+      *K = k; *threads = t; *blocks = nb; *vote_wave = cand_vw[c];
       return RAMX_OK;
     }
   }

@@ -11,9 +11,11 @@
 // device-wide mode: rotating sets of vote shards (row r uses set r % 4; workgroup 0 clears the set of row r+3 during column r,
 // a whole column before anybody adds to it -- see publish / wait_vote in ramx_kernels_cp.h)
 #define RAMX_CP_NSETS 4
-// device-wide mode, blocks of at most this many cells per lane: wave 0 of every workgroup holds no flank (it runs the vote),
-// so a workgroup of T threads holds (T - 64) / K flanks
-#define RAMX_CP_SYNCW_MAXC 11
+// device-wide mode, blocks of at most RAMX_CP_SYNCW_MAXC cells per lane: wave 0 of every workgroup holds no flank (it runs
+// the vote), so a workgroup of T threads holds (T - 64) / K flanks.  The band waves keep the row they may have to restore
+// in registers up to RAMX_CP_SYNCW_REGC cells per lane (workgroups of up to 576 threads), in LDS above (up to 512 threads)
+#define RAMX_CP_SYNCW_MAXC 21
+#define RAMX_CP_SYNCW_REGC 11
 
 struct CpDevDesc
 {
@@ -46,6 +48,7 @@ struct CPArgs
   struct PeerBox *box;          // this rank's own box
   struct PeerBox *mirror;       // host-memory boxes only: device copy kept current by workgroup 0 (NULL: everybody polls `box`)
   int rank, nranks;
+  int vote_wave;       // device-wide mode, blocks of up to RAMX_CP_SYNCW_MAXC cells: 1 = wave 0 of every workgroup runs the vote (ramx_cp_device_plan)
   int test_drop_row;   // test hook (RAMX_TEST_CP_DROP_TICKET=row): the last workgroup of every set withholds its words for that row; 0 = off
 };
 
@@ -60,5 +63,5 @@ int ramx_cp_launch_families(hipStream_t st, int W, int lanes_per_flank, int thre
 // Device-wide mode: lanes per flank and workgroup count for n flanks on `cus` compute units (one 512-thread workgroup per
 // CU at most), 0 lanes if the set does not fit or the width / scoring system is not supported (ramx_cp_max_family > 0).
 // wide: 0 = four band waves per workgroup when the set then fits `cus` workgroups (lowest latency), 1 = the largest workgroup only
-int ramx_cp_device_plan(int W, int n_flanks, int cus, int wide, int *lanes_per_flank, int *threads, int *blocks);
+int ramx_cp_device_plan(int W, int n_flanks, int cus, int wide, int *lanes_per_flank, int *threads, int *blocks, int *vote_wave);
 int ramx_cp_launch_device(hipStream_t st, int W, int lanes_per_flank, int threads, int blocks, const CPArgs &a);

@@ -744,7 +744,7 @@ extern "C" int ramx_dev_run_families(ramx_dev *d, const ramx_flank *flanks, int3
   // Families above one cell-parallel workgroup (group -1): several workgroups per family, the family's vote through its
   // own ticket words -- the device-wide mode of the same kernel, all such families in ONE launch of at most one
   // workgroup per CU (every workgroup must be resident).
-  int n_cp = 0, n_dev = 0, dev_k = 0, dev_threads = 0, cus = 0;
+  int n_cp = 0, n_dev = 0, dev_k = 0, dev_threads = 0, dev_vw = 0, cus = 0;
   std::vector<CpDevDesc> hdev;
   std::vector<int> dev_round_first, dev_round_blocks;   // rounds of at most `cus` workgroups, launched one after the other
   {
@@ -761,7 +761,8 @@ extern "C" int ramx_dev_run_families(ramx_dev *d, const ramx_flank *flanks, int3
     {
       if (fam_count[f] <= cp_max) continue;
       int k = 0, th = 0, nb = 0;
-      ramx_cp_device_plan(W, fam_count[f], cus, 0, &k, &th, &nb);
+      int vwf = 0;
+      ramx_cp_device_plan(W, fam_count[f], cus, 0, &k, &th, &nb, &vwf);
       need += k > 0 ? nb : 0;
     }
     dev_wide = need > cus;
@@ -783,10 +784,11 @@ extern "C" int ramx_dev_run_families(ramx_dev *d, const ramx_flank *flanks, int3
       else if (ok && dev_route)
       {
         int nb = 0;
-        ramx_cp_device_plan(W, fam_count[f], cus, dev_wide, &k, &th, &nb);
-        if (k > 0 && nb <= cus && (dev_k == 0 || (k == dev_k && th == dev_threads)))
+        int vwf = 0;
+        ramx_cp_device_plan(W, fam_count[f], cus, dev_wide, &k, &th, &nb, &vwf);
+        if (k > 0 && nb <= cus && (dev_k == 0 || (k == dev_k && th == dev_threads && vwf == dev_vw)))
         {
-          dev_k = k; dev_threads = th;
+          dev_k = k; dev_threads = th; dev_vw = vwf;
           if (dev_round_first.empty() || dev_round_blocks.back() + nb > cus)
           {
             dev_round_first.push_back((int)hdev.size());
@@ -884,7 +886,7 @@ extern "C" int ramx_dev_run_families(ramx_dev *d, const ramx_flank *flanks, int3
       FAMCHK(hipMemcpyAsync(d->d_devdesc, hdev.data(), sizeof(CpDevDesc) * hdev.size(), hipMemcpyHostToDevice, st));
       FAMCHK(hipMemsetAsync(d->d_vote_sets, 0, sizeof(PShard) * RAMX_CP_NSETS * NSHARD * (size_t)n_families, st));
       FAMCHK(hipMemsetAsync(d->d_err_sets, 0, 64 * (size_t)n_families, st));
-      ca.dev = d->d_devdesc; ca.vote = d->d_vote_sets; ca.err = d->d_err_sets;
+      ca.dev = d->d_devdesc; ca.vote = d->d_vote_sets; ca.err = d->d_err_sets; ca.vote_wave = dev_vw;
 #ifdef RAMX_CP_TIMING
       if (n_cp == 0)
       {
@@ -1090,12 +1092,12 @@ extern "C" int ramx_dev_run_direction(ramx_dev *d, ramx_run_info *info)
   if (!tracing && cp_multi_ok && !d->force_chain && L > 0 && getenv("RAMX_NO_PERSISTENT") == NULL && getenv("RAMX_NO_CP_DEVICE") == NULL &&
       (multi || d->Nx > 0))
   {
-    int dev = 0, cus = 0, k = 0, th = 0, nb = 0;
+    int dev = 0, cus = 0, k = 0, th = 0, nb = 0, vwf = 0;
     HIPCHK(hipGetDevice(&dev));
     HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     const char *mx = getenv("RAMX_CP_DEVICE_MAXN");
     if (d->cp_flanks_ok && ramx_cp_max_family(a.W, a.go, a.ge, d->tab, L) > 0 && (mx == NULL || d->Nx <= atoi(mx)))
-      ramx_cp_device_plan(a.W, d->Nx > 0 ? d->Nx : 1, cus, 0, &k, &th, &nb);
+      ramx_cp_device_plan(a.W, d->Nx > 0 ? d->Nx : 1, cus, 0, &k, &th, &nb, &vwf);
     if (multi)
     {
       // my mailbox is cleared BEFORE the agreement, which no remote launch can get past without my taking part
@@ -1137,7 +1139,7 @@ extern "C" int ramx_dev_run_direction(ramx_dev *d, ramx_run_info *info)
           HIPCHK(hipMemcpyAsync(d->d_devdesc, hd.data(), sizeof(CpDevDesc) * (size_t)nb, hipMemcpyHostToDevice, d->stream));
           HIPCHK(hipStreamSynchronize(d->stream));       // hd goes out of scope
         }
-        ca.dev = d->d_devdesc; ca.vote = d->d_vote; ca.err = d->d_err; ca.S = d->d_state[0];
+        ca.dev = d->d_devdesc; ca.vote = d->d_vote; ca.err = d->d_err; ca.S = d->d_state[0]; ca.vote_wave = vwf;
         { const char *td = getenv("RAMX_TEST_CP_DROP_TICKET"); ca.test_drop_row = td ? atoi(td) : 0; }
         ca.nranks = 1; ca.rank = 0;
         if (multi)

@@ -150,8 +150,9 @@ struct CpCfg
   // because the scan / reduction / vote cost is per wave (tools/cp_cmp_k.sh: 100 flanks at W = 40: 2.58 us per column
   // with 4 lanes per flank, 2.95 with 8).  Blocks of up to 41 cells fit that register budget.
   static constexpr int MAXT = C <= 41 ? 512 : 0;
-  // device-wide mode with a vote wave (RAMX_CP_SYNCW_MAXC): eight band waves and the vote wave
-  static constexpr int MAXT_DEV = C <= RAMX_CP_SYNCW_MAXC ? 576 : MAXT;
+  // device-wide mode with a vote wave (RAMX_CP_SYNCW_MAXC): eight band waves and the vote wave while the saved row fits
+  // the registers of nine waves (168 each); seven band waves and the vote wave when it is kept in LDS
+  static constexpr int MAXT_DEV = C <= RAMX_CP_SYNCW_REGC ? 576 : MAXT;
 };
 
 // per-lane constants of the cell-parallel band
@@ -351,7 +352,8 @@ void ramx_cp_kernel(const CPArgs a)
 {
   typedef CpCfg<W, K> Cfg;
   constexpr int B = Cfg::B, C = Cfg::C, NA = Cfg::NA, NWL = Cfg::NWL, FPW = 64 / K;
-  constexpr bool SYNCW = DEV && C <= RAMX_CP_SYNCW_MAXC;  // device-wide mode with short blocks: a dedicated vote wave, speculative columns
+  constexpr bool SYNCW = DEV && C <= RAMX_CP_SYNCW_MAXC;  // device-wide mode, blocks of up to 21 cells: may run with a dedicated vote wave and speculative columns
+  const bool vw = SYNCW && (C <= RAMX_CP_SYNCW_REGC || a.vote_wave != 0);   // (blocks of 12..21 cells: the host chooses, ramx_cp_device_plan)
   static_assert(K == 2 || K == 4 || K == 8 || K == 16, "lanes per flank");
   static_assert(B <= 255, "cell index must fit the key's low byte");
   struct Smem
@@ -359,6 +361,8 @@ void ramx_cp_kernel(const CPArgs a)
     CpTabs tabs;                                     // first: the table rows are addressed with 16-bit immediate offsets
     unsigned long long vote[3][4];                   // DEV: [0..1] = this workgroup's partial sums (double buffered), [2] = the device-wide vote
     int fail, dec, pad[2];                          // dec: the vote wave's decision word for the band waves (SYNCW)
+    // SYNCW, blocks of 12..21 cells: the row a band wave may have to restore (m then e, four values per 16-byte slot)
+    int4 save[(SYNCW && C > RAMX_CP_SYNCW_REGC) ? (2 * C + 3) / 4 : 1][(SYNCW && C > RAMX_CP_SYNCW_REGC) ? 448 : 1];
   };
   __shared__ __attribute__((aligned(16))) Smem sm;
   // wave index through readfirstlane: `live` must be PROVABLY wave-uniform, or the band sits in a divergent region and
@@ -371,7 +375,7 @@ void ramx_cp_kernel(const CPArgs a)
   {
     // workgroup b of a set holds (band waves) * 64 / K consecutive flanks of it
     dd = a.dev[blockIdx.x];
-    const int per = (blockDim.x - (SYNCW ? 64 : 0)) / K;
+    const int per = (blockDim.x - (vw ? 64 : 0)) / K;
     fd.tile0 = 0; fd.ntiles = 0; fd.id = dd.id;
     fd.nx = dd.nx - dd.b * per;                      // flanks (of this workgroup) that exist
     fd.nx = fd.nx < 0 ? 0 : (fd.nx > per ? per : fd.nx);
@@ -381,10 +385,10 @@ void ramx_cp_kernel(const CPArgs a)
   PShard *const vote = a.vote + (size_t)dd.id * RAMX_CP_NSETS * NSHARD;      // DEV only
   unsigned *const errw = a.err + (size_t)dd.id * 16;
   // SYNCW: wave 0 holds no flank -- it runs the device-wide vote (sync_column below) while waves 1.. run the band
-  const int f = SYNCW ? (wave > 0 ? ((int)threadIdx.x - 64) / K : 0) : threadIdx.x / K;   // flank inside the family / workgroup
-  const bool live = SYNCW ? (wave > 0 && (wave - 1) * FPW < fd.nx) : (wave * FPW < fd.nx);  // wave-uniform: does this wave hold any flank?
+  const int f = vw ? (wave > 0 ? ((int)threadIdx.x - 64) / K : 0) : threadIdx.x / K;   // flank inside the family / workgroup
+  const bool live = vw ? (wave > 0 && (wave - 1) * FPW < fd.nx) : (wave * FPW < fd.nx);  // wave-uniform: does this wave hold any flank?
   const bool active = live && f < fd.nx;
-  const int n = DEV ? dd.first + wg * ((int)(blockDim.x - (SYNCW ? 64 : 0)) / K) + (live ? f : 0) : fd.tile0 * 64 + (live ? f : 0);
+  const int n = DEV ? dd.first + wg * ((int)(blockDim.x - (vw ? 64 : 0)) / K) + (live ? f : 0) : fd.tile0 * 64 + (live ? f : 0);
   const int my_shard_blocks = DEV ? (dd.nb - (lane & (NSHARD - 1)) + NSHARD - 1) / NSHARD : 0;   // wave 0: blocks arriving on shard lane & 31
   int failed = 0;
 
@@ -868,14 +872,53 @@ void ramx_cp_kernel(const CPArgs a)
     constexpr bool G = decltype(gc)::value;
     CP_TICK(7);                  // barrier released .. loop top
     int bestA[4] = { 0, 0, 0, 0 }, bestF = 0, jb = 0;
-    int sm_[C], se_[C];
+    constexpr bool SAVE_LDS = C > RAMX_CP_SYNCW_REGC;
+    int sm_[SAVE_LDS ? 1 : C], se_[SAVE_LDS ? 1 : C];
     int high1 = high, pos1 = pos;
+    // the row before this column: in registers, or (longer blocks) in this thread's column of the LDS save area
+    auto row_value = [&](auto qc) __attribute__((always_inline)) -> int &
+    {
+      constexpr int q = decltype(qc)::value;         // 0 .. C-1: m, C .. 2C-1: e
+      if constexpr (q < C) return m[q]; else return e[q - C];
+    };
+    auto save_row = [&]() __attribute__((always_inline))
+    {
+      if constexpr (!SAVE_LDS)
+        static_for([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value; sm_[i] = m[i]; se_[i] = e[i]; },
+                   std::make_integer_sequence<int, C>{});
+      else
+        static_for([&](auto gc) __attribute__((always_inline))
+        {
+          constexpr int g = decltype(gc)::value;
+          int4 v = make_int4(0, 0, 0, 0);
+          v.x = row_value(std::integral_constant<int, 4 * g>{});
+          if constexpr (4 * g + 1 < 2 * C) v.y = row_value(std::integral_constant<int, (4 * g + 1 < 2 * C ? 4 * g + 1 : 0)>{});
+          if constexpr (4 * g + 2 < 2 * C) v.z = row_value(std::integral_constant<int, (4 * g + 2 < 2 * C ? 4 * g + 2 : 0)>{});
+          if constexpr (4 * g + 3 < 2 * C) v.w = row_value(std::integral_constant<int, (4 * g + 3 < 2 * C ? 4 * g + 3 : 0)>{});
+          sm.save[g][threadIdx.x - 64] = v;
+        }, std::make_integer_sequence<int, (2 * C + 3) / 4>{});
+    };
+    auto restore_row = [&]() __attribute__((always_inline))
+    {
+      if constexpr (!SAVE_LDS)
+        static_for([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value; m[i] = sm_[i]; e[i] = se_[i]; },
+                   std::make_integer_sequence<int, C>{});
+      else
+        static_for([&](auto gc) __attribute__((always_inline))
+        {
+          constexpr int g = decltype(gc)::value;
+          const int4 v = sm.save[g][threadIdx.x - 64];
+          row_value(std::integral_constant<int, 4 * g>{}) = v.x;
+          if constexpr (4 * g + 1 < 2 * C) row_value(std::integral_constant<int, (4 * g + 1 < 2 * C ? 4 * g + 1 : 0)>{}) = v.y;
+          if constexpr (4 * g + 2 < 2 * C) row_value(std::integral_constant<int, (4 * g + 2 < 2 * C ? 4 * g + 2 : 0)>{}) = v.z;
+          if constexpr (4 * g + 3 < 2 * C) row_value(std::integral_constant<int, (4 * g + 3 < 2 * C ? 4 * g + 3 : 0)>{}) = v.w;
+        }, std::make_integer_sequence<int, (2 * C + 3) / 4>{});
+    };
     unsigned contrib[4] = { 0, 0, 0, 0 };
     if (live)
     {
       if (G) set_masks(r);
-      static_for([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value; sm_[i] = m[i]; se_[i] = e[i]; },
-                 std::make_integer_sequence<int, C>{});
+      save_row();
       band(r, guess_cur, gc, bestF, jb, bestA);
       if (bestF > high1) { high1 = bestF; pos1 = r + jb - W; }   // ram_extend.c:1140-1150
       contributions(bestA, high1, contrib);
@@ -896,8 +939,7 @@ void ramx_cp_kernel(const CPArgs a)
     {
       if (wrong)
       {
-        static_for([&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value; m[i] = sm_[i]; e[i] = se_[i]; },
-                   std::make_integer_sequence<int, C>{});
+        restore_row();
         band(r, besta, gc, bestF, jb, bestA);
         high1 = high; pos1 = pos;
         if (bestF > high1) { high1 = bestF; pos1 = r + jb - W; }
@@ -931,11 +973,11 @@ void ramx_cp_kernel(const CPArgs a)
     if (wave == 0) return sync_column(r);
     return band_column(r, gc);
   };
-  if (SYNCW && a.L > 0) guess_cur = argmax4_lds(sm.vote[0]);     // row 0's workgroup sums (complete since the barrier of column -1)
+  if (vw && a.L > 0) guess_cur = argmax4_lds(sm.vote[0]);     // row 0's workgroup sums (complete since the barrier of column -1)
   auto column = [&](const int r, auto gc) __attribute__((always_inline)) -> bool
   {
     constexpr bool G = decltype(gc)::value;
-    if constexpr (SYNCW) return column_spec(r, gc);
+    if constexpr (SYNCW) { if (vw) return column_spec(r, gc); }
     CP_TICK(7);                  // barrier released .. loop top
     int bestA[4] = { 0, 0, 0, 0 }, bestF = 0, jb = 0;
     if (G && live) set_masks(r);
