@@ -178,7 +178,11 @@ def test_cp_scoring_bounds_fall_back(monkeypatch):
 # ---- device-wide mode: one flank set over many workgroups, vote through the ticketed shard words ----------------
 
 @pytest.mark.parametrize("W,n,K,matrix", [(40, 1000, 16, "14p43g"), (40, 5000, 16, "14p43g"), (14, 3000, 16, "20p43g"),
-                                          (80, 2500, 16, "20p43g"), (20, 20000, 4, "repeatscout"), (40, 700, 16, "25p43g")])
+                                          (80, 2500, 16, "20p43g"), (20, 20000, 4, "repeatscout"), (40, 700, 16, "25p43g"),
+                                          (40, 12000, 8, "18p43g"),     # eight band waves + vote wave, saved row in registers
+                                          (40, 20000, 4, "14p43g"),     # 21 cells per lane: seven band waves + vote wave, saved row in LDS
+                                          (40, 30000, 4, "18p43g"),     # 21 cells per lane at the capacity edge: vote, then band (no vote wave)
+                                          (80, 10000, 8, "20p43g")])    # W = 80, 21 cells per lane, vote wave
 def test_cp_device_wide_equals_oracle(W, n, K, matrix):
     """Flank sets above one workgroup (BASELINE config 2's N = 1,000 among them): the cell-parallel kernel in device-wide
     mode, both directions, mixed strands and N runs, against the oracle."""
