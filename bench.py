@@ -30,7 +30,7 @@ from repeatafterme_amd import _lib  # noqa: E402  (loads libramx before torch: s
 from repeatafterme_amd.datamodel import ExtendParams  # noqa: E402
 from repeatafterme_amd.device import Device, resolve_flanks  # noqa: E402
 from repeatafterme_amd.scoring import get_matrix  # noqa: E402
-from repeatafterme_amd.synth import synth_family  # noqa: E402
+from repeatafterme_amd.synth import result_digest as synth_digest, synth_family, writeback_from_trim  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # VALU issue: 256 CUs x 4 SIMDs, 2.4 GHz, a wave64 VALU instruction every 2 cycles per SIMD (MI355X_MICROARCH.md,
@@ -74,10 +74,48 @@ def cpu_baseline(fs, p: ExtendParams, n_sample: int, cols: int):
         r = po.oracle_extend(1, sub, seq, m, pp)
         rows = r.rows_executed
     dt = time.perf_counter() - t0
-    return {"value": rows * n_sample / dt, "unit": "flank-bp/s", "cores": 1, "kind": kind,
+    return {"value": rows * n_sample / dt, "unit": "flank-bp/s", "cores": 1, "host": host_cpu(), "kind": kind,
             "sample": f"first {n_sample} flanks of the same set, {rows} columns, right extension, "
                       f"W={p.bandwidth}, single thread, {dt:.1f} s",
             "columns_per_sec_at_sample_N": rows / dt}, m, sub
+
+
+def self_launch(n: int) -> int:
+    """Started as `python3 bench.py --gpus N` (N > 1) without a launcher: run the N ranks as children of a
+    torch.distributed.run child (fresh processes: this parent never initialises HIP, and nothing is exec'ed after a
+    HIP call) and return its exit code.  Fewer devices than ranks is an error, never a silent 1-GPU run; the only
+    exception is the explicit over-subscribed rehearsal RAMX_BENCH_BACKEND=gloo (several ranks on one GPU, mailboxes
+    through the same code path, host collectives through gloo because RCCL refuses two ranks per device)."""
+    import socket
+    import subprocess
+    import torch
+    ndev = torch.cuda.device_count()            # does not create a HIP context
+    if os.environ.get("RAMX_BENCH_BACKEND", "nccl") == "nccl" and ndev < n:
+        print(f"bench: --gpus {n} but only {ndev} device(s) visible on this node", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
+def host_cpu():
+    """CPU model and core count of the host the cpu_baseline runs on."""
+    model = None
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count()
+    return {"model": model, "logical_cpus": os.cpu_count(), "usable_cpus": usable}
 
 
 def main():
@@ -99,13 +137,17 @@ def main():
                          "take the far-end-masked band; the headline workload uses full-length flanks (0)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))        # `python3 bench.py --gpus N` with no launcher: start the N ranks ourselves
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"bench: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a line for a different rank count")
 
     import torch
+    if world > 1 and os.environ.get("RAMX_BENCH_BACKEND", "nccl") == "nccl" and torch.cuda.device_count() < world:
+        raise SystemExit(f"bench: {world} ranks asked for, {torch.cuda.device_count()} devices visible")
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -182,12 +224,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    import hashlib
-
     def result_digest():
+        # the digest format of tests/golden/fullsize_digests.json (the compiled reference's results on this workload)
         cons, th, tp = dev.download()
-        return hashlib.sha1(np.ascontiguousarray(cons).tobytes() + np.ascontiguousarray(th).tobytes()
-                            + np.ascontiguousarray(tp).tobytes()).hexdigest()
+        ext, sc = writeback_from_trim(th, tp)
+        return synth_digest(dev.last.ret, cons, ext, sc)
 
     infos = []
     digest0 = None
@@ -236,10 +277,12 @@ def main():
         abytes = per_col_bytes
     alg_gbps = abytes / (kavg_ms * 1e-3) / 1e9 if kavg_ms > 0 else 0.0
     us_col = loop_ms * 1e3 / max(rows, 1)
-    # PMC figures (profiles/pmc_summary.json) are valid only for the configuration they were collected on
+    # PMC figures are valid only for the configuration they were collected on: profiles/pmc_summary.json (the headline
+    # lane-per-flank configuration) and the per-configuration list profiles/pmc_configs.json (cell-parallel shapes)
     traffic = None
     valu = None
     insts_per_col = None
+    pmc_source = None
     pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
     if os.path.exists(pmc) and world == 1:
         try:
@@ -259,8 +302,22 @@ def main():
                 cols_prof = ent.get("columns_per_launch") or (ent["hbm_bytes_per_launch"] / ent["hbm_bytes_per_column"] if ent.get("hbm_bytes_per_column") else None)
                 if cnt.get("SQ_INSTS_VALU") and cols_prof:
                     insts_per_col = cnt["SQ_INSTS_VALU"] / (cols_prof if persistent else 1.0)
+                    pmc_source = "profiles/pmc_summary.json"
         except Exception:
             traffic = None
+    pmc2 = os.path.join(ROOT, "profiles", "pmc_configs.json")
+    if insts_per_col is None and os.path.exists(pmc2):
+        try:
+            for ent in json.load(open(pmc2)).get("entries", []):
+                if (ent.get("flanks_per_rank") == N and ent.get("bandwidth") == W and ent.get("lanes_per_flank") == lanes
+                        and bool(ent.get("persistent")) == bool(persistent) and ent.get("ranks", 1) == world):
+                    insts_per_col = ent["SQ_INSTS_VALU_per_column"]
+                    if ent.get("hbm_bytes_per_column") is not None:
+                        traffic = ent["hbm_bytes_per_column"] * rows / n_launch if persistent else ent["hbm_bytes_per_column"]
+                    pmc_source = "profiles/pmc_configs.json:" + ent.get("tag", "")
+                    break
+        except Exception:
+            pass
     if insts_per_col:
         ginst = insts_per_col / (us_col * 1e-6) / 1e9           # wave64 VALU instructions per second, whole chip
         mix = None
@@ -268,19 +325,25 @@ def main():
             mix = json.load(open(os.path.join(ROOT, "profiles", "r02_valu_mix_persistent.json")))
         except Exception:
             pass
-        valu = {"insts_per_column": insts_per_col, "G_wave_inst_per_sec": ginst,
+        valu = {"insts_per_column": insts_per_col, "G_wave_inst_per_sec": ginst, "pmc_source": pmc_source,
                 "peak_guide_2cycle": VALU_PEAK_GINST, "frac_guide_2cycle": ginst / VALU_PEAK_GINST}
-        if mix and persistent:
+        if mix and persistent and lanes == 1:
             # instruction-mix-weighted issue cost of the band (static mix of the hot blocks x measured ticks per opcode class)
             tpi = mix["hot_blocks_ticks_per_valu"]
             valu["measured_ticks_per_inst"] = tpi
             valu["frac_at_measured_issue_cost"] = insts_per_col * tpi / (N_SIMD * CLOCK_GHZ * 1e3 * us_col)
             valu["note"] = ("only v_add/sub/and/or/mov (VGPR operands) issue every 2 cycles on gfx950; v_max3, SDWA, DPP, v_lshl_or, "
                             "v_cndmask take 4 (profiles/r02_valu_rate.log): at the kernel's own mix the chip's issue slots are this "
-                            "fraction busy over the whole column, barrier wait and the 60 CUs without a workgroup included")
+                            "fraction busy over the whole column, barrier wait and the CUs without a workgroup included")
         roof = {"bound": "valu", "achieved": ginst, "peak": VALU_PEAK_GINST, "unit": "G wave64-inst/s", "frac": ginst / VALU_PEAK_GINST}
+    elif persistent:
+        # a register-resident launch with no instruction count for THIS configuration: the rows never move, so there is no
+        # honest byte or instruction rate to quote -- say what was measured (time per column) and nothing else
+        roof = {"bound": "latency" if lanes > 1 else "valu", "achieved": None, "peak": VALU_PEAK_GINST, "unit": "G wave64-inst/s",
+                "frac": None, "note": "no PMC instruction count collected for this (flanks, bandwidth, lanes per flank, ranks); "
+                                      "us_per_column is the measured quantity"}
     else:
-        # no instruction count for this configuration: report the HBM figure of SURVEY 8(d) only
+        # streaming kernel: the rows really are read once and written once per column
         roof = {"bound": "hbm", "achieved": (traffic / (kavg_ms * 1e-3) / 1e9) if (traffic and kavg_ms > 0) else alg_gbps,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None}
         roof["frac"] = roof["achieved"] / HBM_PEAK_GBS
@@ -325,6 +388,26 @@ def main():
         cfg1 = {"workload": "synthetic N=1000 flanks x L=2000 bp, bandwidth=40, right extension, all L columns (BASELINE configs[1])",
                 "us_per_column": best, "columns": r1.rows_executed, "lanes_per_flank": r1.lanes_per_flank, "one_launch": bool(r1.persistent),
                 "flank_bp_per_sec": 1000 * 1e6 / best if best else None}
+    ranks_seen = dist.get_world_size() if dist is not None else 1       # size of the communicator the vote crossed
+    if dist is not None and dist.get_backend() == "nccl":
+        ranks_seen = min(ranks_seen, dev.comm_size())                      # RCCL communicator inside libramx
+    if world == 1:
+        transport = "none (single GPU)"
+    elif peer_path and persistent:
+        transport = "in-kernel mailboxes, " + ("peer device memory (xGMI)" if getattr(dev, "peer_kind", None) == "device" else "registered host shared memory (PCIe)")
+    else:
+        transport = "RCCL all-reduce between column launches" if dist.get_backend() == "nccl" else "host all-reduce (gloo rehearsal hook) between column launches"
+    checks = {"result_sha1": digest1, "same_as_warmup_pass": bool(digest0 is not None)}
+    # reference parity at full size: the compiled reference's digest of this exact workload (tests/golden/make_fullsize_digest.py)
+    gold = os.path.join(ROOT, "tests", "golden", "fullsize_digests.json")
+    if world == 1 and os.path.exists(gold) and args.ragged == 0:
+        for name, g in json.load(open(gold)).items():
+            w = g["workload"]
+            if (w["n"], w["L"], w["W"], w["K"], w["seed"]) == (N, L, W, 1500, 1) and g["when_to_stop"] == L:
+                checks["reference_digest"] = g["sha1"]
+                checks["equals_reference_digest"] = bool(digest1 == g["sha1"])
+                if not checks["equals_reference_digest"]:
+                    raise SystemExit(f"bench: result digest {digest1} differs from the compiled reference's {g['sha1']} ({name})")
     out = {
         "metric": "flank_bp_aligned_per_sec (extension columns/s x flanks)", "value": value, "unit": "flank-bp/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -340,7 +423,8 @@ def main():
                                           else "registered host shared memory over PCIe)")) if (peer_path and persistent)
                                       else "all-reduced with RCCL between column launches")) if world > 1 else "single GPU"},
         "columns_per_sec": cols / dt,
-        "checks": {"result_sha1": digest1, "same_as_warmup_pass": bool(digest0 is not None)},
+        "ranks_seen": ranks_seen, "transport": transport,
+        "checks": checks,
         "cell_updates_per_sec": cols / dt * total_flanks * (2 * W + 1) * 4,
         "roofline": roof,
         "seam1": seam1,

@@ -251,6 +251,8 @@ int ramx_extend_batch(int direction, ramx_family *families, int32_t n_families, 
  * (ramx_comm_unique_id) and handed to the other ranks by the launcher (e.g. torch.distributed). */
 int ramx_comm_unique_id(uint8_t id[128]);
 int ramx_dev_comm_init(ramx_dev *d, const uint8_t id[128], int rank, int nranks);
+/* ranks of the RCCL communicator as RCCL itself counts them (ncclCommCount); 1 without a communicator */
+int ramx_dev_comm_size(ramx_dev *d);
 /* Cross-device persistent path (optional, faster than one RCCL call per column): every rank exports the IPC handle
  * of its mailbox (64 bytes), the launcher all-gathers the handles, every rank imports them; a two-phase self-test
  * (phase 0: write tokens into all boxes -- synchronise the ranks -- phase 1: returns 1 if every rank's token arrived)

@@ -14,7 +14,7 @@ EXPORTS = [
     "ramx_set_runtime", "ramx_extend_alignment", "ramx_extend_flat", "ramx_invalidate_library", "ramx_preload_library", "ramx_resolve_flanks", "ramx_last_error", "ramx_device_count",
     "ramx_dev_create", "ramx_dev_destroy", "ramx_dev_load_library", "ramx_dev_begin_direction",
     "ramx_dev_run_direction", "ramx_dev_download", "ramx_dev_peek_state", "ramx_dev_peek_family_state", "ramx_dev_set_row_trace", "ramx_dev_run_families", "ramx_extend_batch", "ramx_comm_unique_id",
-    "ramx_dev_comm_init", "ramx_dev_set_allreduce_cb", "ramx_dev_peer_export", "ramx_dev_peer_import",
+    "ramx_dev_comm_init", "ramx_dev_comm_size", "ramx_dev_set_allreduce_cb", "ramx_dev_peer_export", "ramx_dev_peer_import",
     "ramx_dev_peer_selftest", "ramx_dev_peer_enable", "ramx_dev_hostbox_attach", "ramx_hostbox_unlink", "ramx_get_matrix", "ramx_get_matrix_using_gap_penalties",
     "ramx_get_repeatscout_matrix", "ramx_free_scoring_system", "ramx_calculate_lambda",
     "ramx_load_sequence_subset_minimal", "ramx_free_library", "ramx_overlap_avoidance",
@@ -95,6 +95,7 @@ def lib() -> C.CDLL:
         L.ramx_dev_peek_family_state.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
         L.ramx_comm_unique_id.argtypes = [C.c_void_p]
         L.ramx_dev_comm_init.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        L.ramx_dev_comm_size.argtypes = [C.c_void_p]
         L.ramx_dev_set_allreduce_cb.argtypes = [C.c_void_p, ALLREDUCE_CB, C.c_void_p]
         L.ramx_dev_peer_export.argtypes = [C.c_void_p, C.c_void_p]
         L.ramx_dev_peer_import.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]

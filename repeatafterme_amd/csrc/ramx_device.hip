@@ -1477,3 +1477,13 @@ extern "C" int ramx_dev_comm_init(ramx_dev *d, const uint8_t id[128], int rank, 
   if (r != ncclSuccess) { ramx_set_error("ncclCommInitRank: %s", ncclGetErrorString(r)); d->comm = NULL; return RAMX_ERR_COMM; }
   return RAMX_OK;
 }
+
+extern "C" int ramx_dev_comm_size(ramx_dev *d)
+{
+  if (!d) { ramx_set_error("ramx_dev_comm_size: bad argument"); return RAMX_ERR_ARG; }
+  if (!d->comm) return 1;
+  int n = 0;
+  ncclResult_t r = ncclCommCount(d->comm, &n);
+  if (r != ncclSuccess) { ramx_set_error("ncclCommCount: %s", ncclGetErrorString(r)); return RAMX_ERR_COMM; }
+  return n;
+}

@@ -88,6 +88,9 @@ class Device:
         uid = np.ascontiguousarray(uid, dtype=np.uint8)
         _lib.check(self._L.ramx_dev_comm_init(self._h, uid.ctypes.data, rank, nranks), "ramx_dev_comm_init")
 
+    def comm_size(self) -> int:
+        return _lib.check(self._L.ramx_dev_comm_size(self._h), "ramx_dev_comm_size")
+
     def set_allreduce_callback(self, fn):
         """Test hook (ramx_dev_set_allreduce_cb): fn(list of 4 ints) -> list of 4 ints summed over ranks."""
         def _cb(ptr, _user):

@@ -187,3 +187,23 @@ def synth_adversarial(seed: int, n_windows: int = 8, L: int = 120, W: int = 14, 
     cores = CoreSet(left_pos=lp, right_pos=rp, lower=lo, upper=up, orient=ori, left_ext=le, right_ext=re_,
                     seq_idx=np.array(sidx, np.int32))
     return FlankSet(sequence=seq, boundaries=np.concatenate((ends, [0])).astype(np.uint64), cores=cores)
+
+
+def result_digest(ret: int, cons: np.ndarray, ext_len: np.ndarray, score: np.ndarray) -> str:
+    """sha1 over what ONE direction of the extension loop hands back (ram_extend.c:1092-1095, 1234-1257): the return
+    value, the consensus byte of every executed column, and per core the extension length and the score increment.
+    bench.py and tests/test_gpu_fullsize.py compare it with the digests of the compiled reference in
+    tests/golden/fullsize_digests.json (written by tests/golden/make_fullsize_digest.py)."""
+    import hashlib
+    h = hashlib.sha1()
+    h.update(np.int32(ret).tobytes())
+    h.update(np.ascontiguousarray(cons, dtype=np.int8).tobytes())
+    h.update(np.ascontiguousarray(ext_len, dtype=np.int32).tobytes())
+    h.update(np.ascontiguousarray(score, dtype=np.int32).tobytes())
+    return h.hexdigest()
+
+
+def writeback_from_trim(trim_high: np.ndarray, trim_pos: np.ndarray):
+    """(extension length, score increment) per flank from the trimmed records, the rule of ram_extend.c:1234-1247."""
+    ok = (trim_high > 0) & (trim_pos >= 0)
+    return np.where(ok, trim_pos + 1, 0).astype(np.int32), np.where(ok, trim_high, 0).astype(np.int32)
