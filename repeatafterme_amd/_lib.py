@@ -41,7 +41,8 @@ class RunInfo(C.Structure):
     _fields_ = [("ret", C.c_int32), ("rows_executed", C.c_int32), ("limit_warning", C.c_int32),
                 ("overflow32", C.c_int32), ("n_extendable", C.c_int32), ("launches", C.c_int32),
                 ("loop_ms", C.c_double), ("kernel_ms_avg", C.c_double), ("kernel_samples", C.c_int32),
-                ("prep_ms", C.c_double), ("persistent", C.c_int32), ("lanes_per_flank", C.c_int32)]
+                ("prep_ms", C.c_double), ("persistent", C.c_int32), ("lanes_per_flank", C.c_int32),
+                ("respeculated_rows", C.c_int32)]
 
 
 class Family(C.Structure):

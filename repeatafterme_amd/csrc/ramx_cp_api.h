@@ -22,8 +22,9 @@ struct CpDevDesc
   int first;        // first flank of the set in the flank arrays
   int nx;           // flanks of the set
   int b, nb;        // this workgroup's index inside the set, workgroups of the set
-  int id;           // set index: vote words at vote + id * RAMX_CP_NSETS * NSHARD, err + id * 16, ctl_out[id], cons_out + id * L
-  int pad[3];
+  int id;           // index of the set's outputs: ctl_out[id], cons_out + id * L
+  int vs;           // index of the set's vote words: vote + vs * RAMX_CP_NSETS * NSHARD, err + vs * 16
+  int pad[2];
 };
 
 struct CPArgs
@@ -50,6 +51,10 @@ struct CPArgs
   int rank, nranks;
   int vote_wave;       // device-wide mode, blocks of up to RAMX_CP_SYNCW_MAXC cells: 1 = wave 0 of every workgroup runs the vote (ramx_cp_device_plan)
   int test_drop_row;   // test hook (RAMX_TEST_CP_DROP_TICKET=row): the last workgroup of every set withholds its words for that row; 0 = off
+  int deep;              // 1: barrier-free variant of the vote-wave mode (band waves several rows ahead, LDS hand-off): RAMX_CP_DEEP=1
+  int test_wrong_every;  // test hook (RAMX_TEST_CP_WRONG_EVERY=n): vote-wave mode, every n-th row is computed on a deliberately wrong guess; 0 = off
+  int test_vote_delay;   // test hook (RAMX_TEST_CP_VOTE_DELAY=units): the vote wave idles that long before every row, so the band waves reach full depth
+  int test_drop_id;    // ... of the set whose outputs index (CpDevDesc.id) is this one only; -1 = every set
 };
 
 #define RAMX_CP_NCLASS 6

@@ -685,6 +685,17 @@ static int prk_run(ramx_dev *d, const KArgs &a, int L, bool *used)
   return rc;
 }
 
+// test hooks of the vote-wave mode of the cell-parallel kernel (ramx_kernels_cp.h): RAMX_TEST_CP_WRONG_EVERY=n computes every
+// n-th row on a deliberately wrong guess, RAMX_TEST_CP_VOTE_DELAY=units holds the vote wave back so that the band waves are
+// DEPTH rows ahead when the decision arrives (rollbacks of full depth)
+static void cp_test_hooks(CPArgs &ca)
+{
+  const char *we = getenv("RAMX_TEST_CP_WRONG_EVERY"), *vd = getenv("RAMX_TEST_CP_VOTE_DELAY"), *dp = getenv("RAMX_CP_DEEP");
+  ca.test_wrong_every = we ? atoi(we) : 0;
+  ca.test_vote_delay = vd ? atoi(vd) : 0;
+  ca.deep = (dp && atoi(dp) != 0) ? 1 : 0;
+}
+
 // ---- batch mode -------------------------------------------------------------------------------
 template <int W, int BLOCK>
 static int fam_launch(ramx_dev *d, const FArgs &fa, int F, hipStream_t st)
@@ -695,9 +706,14 @@ static int fam_launch(ramx_dev *d, const FArgs &fa, int F, hipStream_t st)
   return RAMX_OK;
 }
 
-extern "C" int ramx_dev_run_families(ramx_dev *d, const ramx_flank *flanks, int32_t n_padded, const int32_t *fam_first,
-                                     const int32_t *fam_count, int32_t n_families, const ramx_params *p,
-                                     ramx_run_info *infos, int8_t *cons, int32_t *trim_high, int32_t *trim_pos)
+// One pass over a batch.  allow_dev: families above one cell-parallel workgroup may take the device-wide mode (several
+// workgroups voting through ticket words with a bounded spin).  timed_out[f] != 0 on return: that family's device-wide vote
+// gave up (e.g. its workgroups were not all resident because a co-tenant held CUs) -- its outputs are invalid and the caller
+// repeats it with allow_dev = false; with timed_out == NULL such a family makes the whole call fail.
+static int run_families_pass(ramx_dev *d, const ramx_flank *flanks, int32_t n_padded, const int32_t *fam_first,
+                             const int32_t *fam_count, int32_t n_families, const ramx_params *p,
+                             ramx_run_info *infos, int8_t *cons, int32_t *trim_high, int32_t *trim_pos,
+                             bool allow_dev, unsigned char *timed_out)
 {
   if (!d || !p || !p->matrix || n_families < 0 || n_padded < 0 || (n_padded & 63) || (n_families && (!fam_first || !fam_count || !flanks)))
   { ramx_set_error("ramx_dev_run_families: bad argument"); return RAMX_ERR_ARG; }
@@ -751,7 +767,7 @@ extern "C" int ramx_dev_run_families(ramx_dev *d, const ramx_flank *flanks, int3
     int devo = 0;
     if (hipGetDevice(&devo) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, devo) != hipSuccess) cus = 0;
   }
-  const bool dev_route = cp_max > 0 && cus > 0 && getenv("RAMX_NO_CP_DEVICE") == NULL && getenv("RAMX_NO_PERSISTENT") == NULL;
+  const bool dev_route = allow_dev && cp_max > 0 && cus > 0 && getenv("RAMX_NO_CP_DEVICE") == NULL && getenv("RAMX_NO_PERSISTENT") == NULL;
   // small workgroups (four band waves, lowest latency) when all the multi-workgroup families then fit the CUs together
   int dev_wide = 0;
   if (dev_route)
@@ -799,7 +815,7 @@ extern "C" int ramx_dev_run_families(ramx_dev *d, const ramx_flank *flanks, int3
           {
             CpDevDesc x;
             memset(&x, 0, sizeof(x));
-            x.first = fam_first[f]; x.nx = fam_count[f]; x.b = b; x.nb = nb; x.id = f;
+            x.first = fam_first[f]; x.nx = fam_count[f]; x.b = b; x.nb = nb; x.id = f; x.vs = n_dev;
             hdev.push_back(x);
           }
           n_dev++;
@@ -864,6 +880,18 @@ extern "C" int ramx_dev_run_families(ramx_dev *d, const ramx_flank *flanks, int3
     FAMCHK(hipEventCreateWithFlags(&d->cls_ready, hipEventDisableTiming));
     d->cls_init = 1;
   }
+  if (n_dev > 0)
+  {
+    // everything the device-wide launch needs is uploaded and cleared on the library's stream, BEFORE the fork: the launch
+    // itself is then the first thing the idle device sees, and its workgroups are resident before any other group's
+    // (vote / error words: one set per multi-workgroup family, not per family of the batch)
+    if ((rc = ensure(&d->d_devdesc, &d->cap_devdesc, sizeof(CpDevDesc) * hdev.size()))) goto done;
+    if ((rc = ensure(&d->d_vote_sets, &d->cap_vote_sets, sizeof(PShard) * RAMX_CP_NSETS * NSHARD * (size_t)n_dev))) goto done;
+    if ((rc = ensure(&d->d_err_sets, &d->cap_err_sets, 64 * (size_t)n_dev))) goto done;
+    FAMCHK(hipMemcpyAsync(d->d_devdesc, hdev.data(), sizeof(CpDevDesc) * hdev.size(), hipMemcpyHostToDevice, d->stream));
+    FAMCHK(hipMemsetAsync(d->d_vote_sets, 0, sizeof(PShard) * RAMX_CP_NSETS * NSHARD * (size_t)n_dev, d->stream));
+    FAMCHK(hipMemsetAsync(d->d_err_sets, 0, 64 * (size_t)n_dev, d->stream));
+  }
   FAMCHK(hipEventRecord(d->cls_ready, d->stream));
   // every group stream waits (the register-resident branch below merges shapes AFTER this point: a stream that is
   // launched on must never have skipped the wait -- uploads and the pack kernel run on the library's stream)
@@ -878,15 +906,14 @@ extern "C" int ramx_dev_run_families(ramx_dev *d, const ramx_flank *flanks, int3
     ca.when_to_stop = p->when_to_stop;
     memcpy(ca.tab, tab9, sizeof(ca.tab));
     ca.nranks = 1; ca.rank = 0;
-    if ((rc = ensure(&d->d_devdesc, &d->cap_devdesc, sizeof(CpDevDesc) * hdev.size()))) goto done;
-    if ((rc = ensure(&d->d_vote_sets, &d->cap_vote_sets, sizeof(PShard) * RAMX_CP_NSETS * NSHARD * (size_t)n_families))) goto done;
-    if ((rc = ensure(&d->d_err_sets, &d->cap_err_sets, 64 * (size_t)n_families))) goto done;
     {
       hipStream_t st = d->cls_stream[RAMX_NGROUP - 1];       // shares a stream with the last lane-per-flank shape, enqueued before it
-      FAMCHK(hipMemcpyAsync(d->d_devdesc, hdev.data(), sizeof(CpDevDesc) * hdev.size(), hipMemcpyHostToDevice, st));
-      FAMCHK(hipMemsetAsync(d->d_vote_sets, 0, sizeof(PShard) * RAMX_CP_NSETS * NSHARD * (size_t)n_families, st));
-      FAMCHK(hipMemsetAsync(d->d_err_sets, 0, 64 * (size_t)n_families, st));
       ca.dev = d->d_devdesc; ca.vote = d->d_vote_sets; ca.err = d->d_err_sets; ca.vote_wave = dev_vw;
+      // test hooks: RAMX_TEST_CP_DROP_TICKET=row withholds one workgroup's words for that row, in every multi-workgroup
+      // family or only in family RAMX_TEST_CP_DROP_FAMILY (index in the batch)
+      { const char *td = getenv("RAMX_TEST_CP_DROP_TICKET"), *tf = getenv("RAMX_TEST_CP_DROP_FAMILY");
+        ca.test_drop_row = td ? atoi(td) : 0; ca.test_drop_id = tf ? atoi(tf) : -1; }
+      cp_test_hooks(ca);
 #ifdef RAMX_CP_TIMING
       if (n_cp == 0)
       {
@@ -1038,7 +1065,10 @@ extern "C" int ramx_dev_run_families(ramx_dev *d, const ramx_flank *flanks, int3
   }
   for (int f = 0; f < n_families; f++)
   {
-    if (!infos) { if (grp[f] < 0 && hctl[f].pad != 0) { ramx_set_error("batch mode: the vote of a multi-workgroup family timed out"); rc = RAMX_ERR_STATE; goto done; } continue; }
+    const bool gave_up = grp[f] < 0 && hctl[f].pad != 0;
+    if (timed_out) timed_out[f] = gave_up ? 1 : 0;
+    if (gave_up && !timed_out) { ramx_set_error("batch mode: the vote of a multi-workgroup family timed out (bounded spin gave up)"); rc = RAMX_ERR_STATE; goto done; }
+    if (!infos) continue;
     memset(&infos[f], 0, sizeof(ramx_run_info));
     infos[f].ret = hctl[f].max_row + 1;
     infos[f].rows_executed = hctl[f].rows_done;
@@ -1050,12 +1080,7 @@ extern "C" int ramx_dev_run_families(ramx_dev *d, const ramx_flank *flanks, int3
     /* 1: rows resident in registers (3: of K lanes per flank, the cell-parallel kernel); 2: streaming family kernel */
     infos[f].persistent = grp[f] < RAMX_CP_NCLASS ? 1 : (resident ? 1 : 2);
     infos[f].lanes_per_flank = grp[f] < 0 ? dev_k : (grp[f] < RAMX_CP_NCLASS ? cp_k[grp[f]] : 1);
-    if (grp[f] < 0 && hctl[f].pad != 0)
-    {
-      ramx_set_error("batch mode: the vote of a multi-workgroup family timed out (bounded spin gave up)");
-      rc = RAMX_ERR_STATE;
-      goto done;
-    }
+    infos[f].respeculated_rows = grp[f] < 0 ? hctl[f].besta : 0;
   }
   rc = RAMX_OK;
 done:
@@ -1064,6 +1089,57 @@ done:
   free(hctl); free(tmp); free(hfd); free(grp);
   d->ready = 0;       // the single-family buffers were reused: begin_direction must be called again before run_direction
   return rc;
+}
+
+extern "C" int ramx_dev_run_families(ramx_dev *d, const ramx_flank *flanks, int32_t n_padded, const int32_t *fam_first,
+                                     const int32_t *fam_count, int32_t n_families, const ramx_params *p,
+                                     ramx_run_info *infos, int8_t *cons, int32_t *trim_high, int32_t *trim_pos)
+{
+  std::vector<unsigned char> to((size_t)(n_families > 0 ? n_families : 1), 0);
+  int rc = run_families_pass(d, flanks, n_padded, fam_first, fam_count, n_families, p, infos, cons, trim_high, trim_pos, true, to.data());
+  if (rc != RAMX_OK) return rc;
+  // Batch mode degrades, it does not fail: a multi-workgroup family whose device-wide vote gave up is repeated on the
+  // one-lane-per-flank route (one workgroup per family, block-local vote: nothing to wait for), the other families'
+  // results are kept.
+  std::vector<int> redo;
+  for (int f = 0; f < n_families; f++) if (to[f]) redo.push_back(f);
+  if (redo.empty()) return RAMX_OK;
+  fprintf(stderr, "ramx: batch mode: the device-wide vote of %zu multi-workgroup famil%s timed out (bounded spin); repeating "
+                  "%s on the lane-per-flank route\n", redo.size(), redo.size() == 1 ? "y" : "ies", redo.size() == 1 ? "it" : "them");
+  const int L = p->L;
+  std::vector<ramx_flank> fl2;
+  std::vector<int32_t> first2, count2;
+  for (int f : redo)
+  {
+    first2.push_back((int32_t)fl2.size());
+    count2.push_back(fam_count[f]);
+    const int padded = ((fam_count[f] + 63) / 64) * 64;
+    for (int i = 0; i < padded; i++)
+    {
+      ramx_flank x;
+      if (i < fam_count[f]) x = flanks[fam_first[f] + i];
+      else { memset(&x, 0, sizeof(x)); x.t_lo = 1; x.t_hi = 0; x.step = 1; }      // empty padding flank
+      fl2.push_back(x);
+    }
+  }
+  const int n2 = (int)redo.size(), np2 = (int)fl2.size();
+  std::vector<ramx_run_info> inf2((size_t)n2);
+  std::vector<int8_t> cons2((size_t)n2 * (L > 0 ? L : 1));
+  std::vector<int32_t> th2((size_t)np2 + 1), tp2((size_t)np2 + 1);
+  rc = run_families_pass(d, fl2.data(), np2, first2.data(), count2.data(), n2, p, inf2.data(), cons2.data(), th2.data(), tp2.data(), false, NULL);
+  if (rc != RAMX_OK) return rc;
+  for (int k = 0; k < n2; k++)
+  {
+    const int f = redo[k];
+    if (infos) infos[f] = inf2[k];
+    if (cons && L > 0) memcpy(cons + (size_t)f * L, cons2.data() + (size_t)k * L, (size_t)L);
+    for (int i = 0; i < fam_count[f]; i++)
+    {
+      if (trim_high) trim_high[fam_first[f] + i] = th2[first2[k] + i];
+      if (trim_pos) trim_pos[fam_first[f] + i] = tp2[first2[k] + i];
+    }
+  }
+  return RAMX_OK;
 }
 
 extern "C" int ramx_dev_run_direction(ramx_dev *d, ramx_run_info *info)
@@ -1140,7 +1216,8 @@ extern "C" int ramx_dev_run_direction(ramx_dev *d, ramx_run_info *info)
           HIPCHK(hipStreamSynchronize(d->stream));       // hd goes out of scope
         }
         ca.dev = d->d_devdesc; ca.vote = d->d_vote; ca.err = d->d_err; ca.S = d->d_state[0]; ca.vote_wave = vwf;
-        { const char *td = getenv("RAMX_TEST_CP_DROP_TICKET"); ca.test_drop_row = td ? atoi(td) : 0; }
+        { const char *td = getenv("RAMX_TEST_CP_DROP_TICKET"); ca.test_drop_row = td ? atoi(td) : 0; ca.test_drop_id = -1; }
+        cp_test_hooks(ca);
         ca.nranks = 1; ca.rank = 0;
         if (multi)
         {
@@ -1157,12 +1234,30 @@ extern "C" int ramx_dev_run_direction(ramx_dev *d, ramx_run_info *info)
         HIPCHK(hipMemsetAsync(d->d_vote, 0, RAMX_CP_NSETS * NSHARD * sizeof(PShard), d->stream));
         HIPCHK(hipMemsetAsync(d->d_err, 0, 64, d->stream));
         HIPCHK(hipMemsetAsync(d->d_ctl, 0, 2 * sizeof(RamxCtl), d->stream));
+#ifdef RAMX_CP_TIMING
+        HIPCHK(hipMalloc((void **)&ca.dbg, (16 * 16 + 8) * sizeof(unsigned long long)));
+        HIPCHK(hipMemset(ca.dbg, 0, (16 * 16 + 8) * sizeof(unsigned long long)));
+#endif
         HIPCHK(hipEventRecord(d->ev_begin, d->stream));
         if (multi) test_delay_rank(d);
         int crc = ramx_cp_launch_device(d->stream, a.W, k, th, nb, ca);
         if (crc != RAMX_OK) { ramx_set_error("cell-parallel device launch failed (W %d, %d lanes per flank, %d workgroups)", a.W, k, nb); return crc; }
         HIPCHK(hipEventRecord(d->ev_end, d->stream));
         HIPCHK(hipStreamSynchronize(d->stream));
+#ifdef RAMX_CP_TIMING
+        if (vwf)
+        {
+          unsigned long long h[16 * 16 + 8];
+          HIPCHK(hipMemcpy(h, ca.dbg, sizeof(h), hipMemcpyDeviceToHost));
+          const double cols = h[16 * 16] ? (double)h[16 * 16] : 1.0;
+          fprintf(stderr, "SP_TIMING workgroup 0, %d workgroups x %d threads, K %d, %.0f rows; shader clocks (100 MHz) per row\n", nb, th, k, cols);
+          fprintf(stderr, "SP_TIMING vote wave: tickets wait+fold %.1f | winner+forward %.1f | stop rule, decision %.1f | loop %.1f | waiting for band sums %.1f | forwarded at once %.0f %%\n",
+                  h[0] / cols, h[1] / cols, h[2] / cols, h[3] / cols, h[4] / cols, 100.0 * h[5] / cols);
+          for (int wv = 1; wv < th / 64; wv++)
+            fprintf(stderr, "SP_TIMING band wave %d: idle %.1f | planning %.1f | rows %.1f\n", wv, h[wv * 16 + 0] / cols, h[wv * 16 + 1] / cols, h[wv * 16 + 2] / cols);
+        }
+        (void)hipFree(ca.dbg);
+#endif
         return RAMX_OK;
       };
       lrc = launch();
@@ -1183,7 +1278,14 @@ extern "C" int ramx_dev_run_direction(ramx_dev *d, ramx_run_info *info)
           d->peer_ready = 0;        // agreed by all ranks (the flag above is reduced)
         }
       }
-      else if (lrc != RAMX_OK) return lrc;
+      else if (lrc != RAMX_OK)
+      {
+        // single GPU: the other routes can serve the same flank set -- an occupancy query that says no, a launch error of
+        // this one instantiation -- so a local failure here is not the direction's failure
+        (void)hipStreamSynchronize(d->stream);
+        (void)hipGetLastError();
+        fprintf(stderr, "ramx: cell-parallel device launch not possible (%s); continuing on the lane-per-flank route\n", ramx_last_error());
+      }
       else if (bad)
         fprintf(stderr, "ramx: device-wide vote of the cell-parallel launch timed out (bounded spin); repeating the direction with "
                         "per-column launches\n");
@@ -1362,6 +1464,7 @@ extern "C" int ramx_dev_run_direction(ramx_dev *d, ramx_run_info *info)
     info->kernel_samples = cnt;
     info->persistent = persistent ? 1 : 0;
     info->lanes_per_flank = lanes;
+    info->respeculated_rows = cp_done ? f.besta : 0;
   }
   return RAMX_OK;
 }

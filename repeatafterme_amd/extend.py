@@ -30,6 +30,7 @@ class RunInfo:
     prep_ms: float
     persistent: int = 0
     lanes_per_flank: int = 1
+    respeculated_rows: int = 0
 
 
 def _params(p: ExtendParams):
