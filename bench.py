@@ -387,7 +387,16 @@ def main():
             best = us if best is None else min(best, us)
         cfg1 = {"workload": "synthetic N=1000 flanks x L=2000 bp, bandwidth=40, right extension, all L columns (BASELINE configs[1])",
                 "us_per_column": best, "columns": r1.rows_executed, "lanes_per_flank": r1.lanes_per_flank, "one_launch": bool(r1.persistent),
+                "columns_computed_twice_after_a_wrong_guess": r1.respeculated_rows,
                 "flank_bp_per_sec": 1000 * 1e6 / best if best else None}
+        gold1 = os.path.join(ROOT, "tests", "golden", "fullsize_digests.json")
+        if os.path.exists(gold1) and "cfg2" in json.load(open(gold1)):
+            g1 = json.load(open(gold1))["cfg2"]
+            d1 = synth_digest(r1.ret, m1[2001:4001], c1.right_len, c1.score)
+            cfg1["result_sha1"] = d1
+            cfg1["equals_reference_digest"] = bool(d1 == g1["sha1"])
+            if d1 != g1["sha1"]:
+                raise SystemExit(f"bench: configs[1] result digest {d1} differs from the compiled reference's {g1['sha1']}")
     ranks_seen = dist.get_world_size() if dist is not None else 1       # size of the communicator the vote crossed
     if dist is not None and dist.get_backend() == "nccl":
         ranks_seen = min(ranks_seen, dev.comm_size())                      # RCCL communicator inside libramx

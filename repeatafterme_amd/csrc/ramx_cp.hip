@@ -132,14 +132,21 @@ int ramx_cp_device_plan(int W, int n, int cus, int wide, int *K, int *threads, i
     // row lives in registers, seven when it lives in LDS -- and for those, before giving up lanes per flank, the plain
     // order without a vote wave (eight band waves again).
     const bool syncw = cells <= RAMX_CP_SYNCW_MAXC, regs = cells <= RAMX_CP_SYNCW_REGC;
-    int cand_t[3], cand_vw[3], nc = 0;
+    int cand_t[4], cand_vw[4], nc = 0;
     if (ftv)
     {
       const int vw = syncw && (regs || !no_vw);
       const int tbig = vw ? (regs ? tmax + 64 : tmax) : tmax;
       cand_t[nc] = ftv < (vw ? 128 : 64) ? (vw ? 128 : 64) : (ftv > tbig ? tbig : ftv); cand_vw[nc++] = vw;
     }
-    else if (syncw && regs) { if (!wide) { cand_t[nc] = 320; cand_vw[nc++] = 1; } cand_t[nc] = tmax + 64; cand_vw[nc++] = 1; }
+    else if (syncw && regs)
+    {
+      // three band waves and the vote wave: every wave has a SIMD to itself, which shortens the vote wave's chain by more than
+      // the larger number of workgroups costs (profiles/r03_ab_threads.log: N = 1,000: 1.43 us per column against 1.58 with
+      // four band waves, N = 3,000: 1.50 against 1.62)
+      if (!wide) { cand_t[nc] = 256; cand_vw[nc++] = 1; cand_t[nc] = 320; cand_vw[nc++] = 1; }
+      cand_t[nc] = tmax + 64; cand_vw[nc++] = 1;
+    }
     else if (syncw)
     {
       if (!no_vw) { if (!wide) { cand_t[nc] = 320; cand_vw[nc++] = 1; } cand_t[nc] = tmax; cand_vw[nc++] = 1; }

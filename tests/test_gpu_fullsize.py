@@ -76,17 +76,45 @@ def test_full_run_properties(family):
     assert np.array_equal(c3.right_len, c.right_len[perm]) and np.array_equal(c3.score, c.score[perm])
 
 
-def test_forced_full_length_run_is_deterministic(family):
-    """stopafter = L forces all 10,000 columns (the bench workload); two runs agree on every output."""
+def _reference_digest(name):
+    import json, os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fullsize_digests.json")
+    return json.load(open(path))[name]
+
+
+def test_forced_full_length_run_equals_the_reference_digest(family):
+    """stopafter = L forces all 10,000 columns (the bench workload).  The digest of (return value, all 10,000 consensus
+    bytes, 100,000 extension lengths, 100,000 scores) equals the one the COMPILED REFERENCE produced on this exact workload
+    (tests/golden/fullsize_digests.json, written by tests/golden/make_fullsize_digest.py from oracle/_ref/libramref.so:
+    4,586 s of ram_extend.c:859-1258 on one core): reference parity over the whole run, not a prefix.  Two runs agree."""
+    from repeatafterme_amd.synth import result_digest
     fs = family
+    g = _reference_digest("cfg3")
+    assert (g["workload"]["n"], g["workload"]["L"], g["workload"]["W"], g["workload"]["K"], g["workload"]["seed"]) == (N, L, W, K, 1)
     p = po.Params.named("14p43g", bandwidth=W, L=L, when_to_stop=L)
     outs = []
     for _ in range(2):
         c = fs.cores.copy(); m = new_master(L)
         r = gpu_extend(1, c, fs.sequence, m, p)
-        assert r.rows_executed == L and r.ret == K
+        assert r.rows_executed == L and r.ret == K == g["ret"]
+        assert int(c.score.astype(np.int64).sum()) == g["sum_score"] and int(c.right_len.astype(np.int64).sum()) == g["sum_right_len"]
+        assert result_digest(r.ret, m[L + 1:L + 1 + L], c.right_len, c.score) == g["sha1"]
         outs.append((m.copy(), c.right_len.copy(), c.score.copy()))
     assert all(np.array_equal(x, y) for x, y in zip(*outs))
+
+
+def test_config2_full_run_equals_the_reference_digest():
+    """BASELINE configs[1] (N = 1,000 x L = 2,000, all 2,000 columns) against the compiled reference's digest -- the
+    cell-parallel device-wide kernel over the aligned phase, the tail and its mispredicted columns."""
+    from repeatafterme_amd.synth import result_digest
+    g = _reference_digest("cfg2")
+    w = g["workload"]
+    fs = synth_family(w["n"], w["L"], w["W"], K=w["K"], seed=w["seed"])
+    p = po.Params.named("14p43g", bandwidth=w["W"], L=w["L"], when_to_stop=w["L"])
+    c = fs.cores.copy(); m = new_master(w["L"])
+    r = gpu_extend(1, c, fs.sequence, m, p)
+    assert r.rows_executed == w["L"] and r.ret == g["ret"] and r.lanes_per_flank == 16
+    assert result_digest(r.ret, m[w["L"] + 1:2 * w["L"] + 1], c.right_len, c.score) == g["sha1"]
 
 
 @pytest.mark.parametrize("n,route", [(150, "one workgroup"), (1500, "device-wide")])
