@@ -152,6 +152,10 @@ void ramx_invalidate_library(void);
  * copy without looking at the buffer again -- the caller vouches that it does not change until
  * ramx_invalidate_library() or a call with another buffer. */
 int ramx_preload_library(const int8_t *sequence, uint64_t seq_len);
+/* The packed twin of a library loaded with ramx_load_sequence_subset_packed goes to the device; ramx_extend_alignment calls
+ * on that seqLib (whose ->sequence is NULL) then run on it, until ramx_invalidate_library() or another preload. */
+struct ramx_packed_library;
+int ramx_preload_library_packed(const struct sequenceLibrary *seqLib, const struct ramx_packed_library *pl);
 
 /* ------------------------------------------------------------------------------------------
  * Seam 2: thin device API (one ramx_dev per GPU / per process rank)
@@ -174,6 +178,10 @@ void ramx_dev_destroy(ramx_dev *d);                            /* destroy */
 /* upload: the 1-byte-per-base library (seqLib->sequence) goes to HBM once and is shared by both
  * directions. */
 int ramx_dev_load_library(ramx_dev *d, const int8_t *sequence, uint64_t length);
+/* upload of a packed library (ramx_packed_library, below): the pack kernel of every direction then builds the flank windows
+ * straight from the 2-bit payload; the one-byte-per-base form never exists on the host or the device */
+struct ramx_packed_library;
+int ramx_dev_load_library_packed(ramx_dev *d, const struct ramx_packed_library *pl);
 
 /* One flank (an extendable core seen from one direction), already resolved by the host:
  * the base aligned to band cell (row r, offset o) is library[start + step*(o + r)], complemented
@@ -298,6 +306,32 @@ struct sequenceLibrary *ramx_load_sequence_subset_minimal(const char *twoBitName
                                                           struct coreAlignment **core_align,
                                                           int *num_cores, int max_flanking_bp);
 void ramx_free_library(struct sequenceLibrary *lib, struct coreAlignment *cores);
+
+/* The same windows kept as the .2bit file stores them (replaces the expansion to one byte per base of
+ * kentsrc/twoBitNew.c:531-613 + sequence.c:759,812-822): four bases per byte, first base in the most significant bits,
+ * T C A G = 0 1 2 3; runs of N as (start, length) in library coordinates -- the coordinates of seqLib->sequence, i.e. what
+ * coreAlignment.leftSeqPos / lowerSeqBound ... count in.  A quarter of the bytes to read, keep, upload and free. */
+typedef struct ramx_packed_library
+{
+  uint64_t length;             /* bases */
+  int32_t n_windows;
+  const uint64_t *win_start;   /* [n_windows + 1] first base of window i; win_start[n_windows] = length */
+  const uint64_t *win_byte;    /* [n_windows + 1] offset of window i's first packed byte in bytes[] */
+  const uint8_t *win_phase;    /* [n_windows] position (0..3) of the window's first base inside that byte */
+  const uint8_t *bytes;        /* the windows' bytes of the records' packed DNA, window after window */
+  uint64_t n_bytes;
+  const uint64_t *n_start;     /* runs of N, clipped to the windows, sorted */
+  const uint32_t *n_len;
+  int32_t n_blocks;
+} ramx_packed_library;
+
+/* loadSequenceSubsetMinimal without the expansion: lib->sequence is NULL, *packed (owned by the library, released by
+ * ramx_free_library) holds the bases.  Everything else -- identifiers, boundaries, offsets, cores -- as above. */
+struct sequenceLibrary *ramx_load_sequence_subset_packed(const char *twoBitName, const char *rangeBEDName,
+                                                         struct coreAlignment **core_align, int *num_cores,
+                                                         int max_flanking_bp, const ramx_packed_library **packed);
+/* bases [from, from + count) as the reference's codes (A C G T = 0..3, N = 99): what seqLib->sequence would hold there */
+int ramx_packed_decode(const ramx_packed_library *pl, uint64_t from, uint64_t count, char *out);
 
 /* overlap avoidance between the two directions (reference ram_extend.c:445-499), prints the same lines */
 void ramx_overlap_avoidance(struct coreAlignment *coreAlign, struct sequenceLibrary *seqLib);

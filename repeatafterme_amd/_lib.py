@@ -17,7 +17,7 @@ EXPORTS = [
     "ramx_dev_comm_init", "ramx_dev_comm_size", "ramx_dev_set_allreduce_cb", "ramx_dev_peer_export", "ramx_dev_peer_import",
     "ramx_dev_peer_selftest", "ramx_dev_peer_enable", "ramx_dev_hostbox_attach", "ramx_hostbox_unlink", "ramx_get_matrix", "ramx_get_matrix_using_gap_penalties",
     "ramx_get_repeatscout_matrix", "ramx_free_scoring_system", "ramx_calculate_lambda",
-    "ramx_load_sequence_subset_minimal", "ramx_free_library", "ramx_overlap_avoidance",
+    "ramx_load_sequence_subset_minimal", "ramx_load_sequence_subset_packed", "ramx_packed_decode", "ramx_dev_load_library_packed", "ramx_preload_library_packed", "ramx_free_library", "ramx_overlap_avoidance",
     "ramx_print_core_edges", "ramx_allocate_score", "ramx_free_score", "ramx_cli_main",
 ]
 

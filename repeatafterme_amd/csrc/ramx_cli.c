@@ -169,15 +169,16 @@ static double now_s(void)
   return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
 }
 static int g_timing = 0;
-static double g_t_last = 0;
+static double g_t_last = 0, g_t_main = 0;
 static void phase_done(const char *what)
 {
   if (!g_timing) return;
   fflush(stdout);
   const double t = now_s();
-  fprintf(stderr, "RAMX_TIMING %-18s %10.3f ms\n", what, (t - g_t_last) * 1e3);
+  fprintf(stderr, "RAMX_TIMING %-18s %10.3f ms   (at %8.3f ms after main)\n", what, (t - g_t_last) * 1e3, (t - g_t_main) * 1e3);
   g_t_last = t;
 }
+static void timing_at_exit(void) { if (g_timing) { const double t = now_s(); fprintf(stderr, "RAMX_TIMING %-18s %10.3f ms   (at %8.3f ms after main)\n", "first atexit handler", (t - g_t_last) * 1e3, (t - g_t_main) * 1e3); } }
 
 /* The first HIP call of a process costs 0.1-0.3 s (runtime start-up, device context).  It does not depend on the
  * input, so it runs in a helper thread while the loader reads the .2bit; joined before the first extension. */
@@ -198,7 +199,12 @@ static void *warm_device(void *unused)
   while (g_warm_lib == NULL && !g_warm_quit) pthread_cond_wait(&g_warm_cv, &g_warm_mu);
   const struct sequenceLibrary *lib = g_warm_lib;
   pthread_mutex_unlock(&g_warm_mu);
-  if (lib != NULL) (void)ramx_preload_library((const int8_t *)lib->sequence, lib->length);   /* a failure: seam 1 uploads (and reports) itself */
+  if (lib != NULL)                      /* a failure: seam 1 uploads (and reports) itself */
+  {
+    const ramx_packed_library *pl = ramx_packed_of(lib);
+    if (pl) (void)ramx_preload_library_packed(lib, pl);
+    else if (lib->sequence) (void)ramx_preload_library((const int8_t *)lib->sequence, lib->length);
+  }
   return NULL;
 }
 static void warm_offer_library(const struct sequenceLibrary *lib)
@@ -272,35 +278,24 @@ static void print_header(const struct cli_opts *o, const char *ranges_file, int 
   printf("Read in %d ranges, and %ld bp of sequence\n\n", N, (long)lib->length);
 }
 
-/* consensus records, report table, -cons / -outtsv / -outfa: reference ram_extend.c:515-781 */
-static void write_results(const struct cli_opts *o, struct coreAlignment *cores, struct sequenceLibrary *lib, const char *master,
-                          int rightbp, int leftbp, const char *cons_file, const char *outtsv, const char *outfa)
+/* rows [lo_i, hi_i) of the report (stdout), of -outtsv and of -outfa: reference ram_extend.c:606-779 */
+struct results_ctx
 {
-  const int L = o->L, l = 1, flanking = o->flanking;
-  const long masterend = (long)L + l + rightbp;
-  const long masterstart = (long)L - leftbp;
-  if (rightbp > 0 || leftbp > 0)
-  {
-    FILE *fp = NULL, *fp_fa = NULL;
-    if (leftbp > 0) { printf(">left-extension\n"); write_wrapped(stdout, master, (uint64_t)masterstart, (uint64_t)L, (uint64_t)masterstart); }
-    if (rightbp > 0) { printf(">right-extension\n"); write_wrapped(stdout, master, (uint64_t)L + l, (uint64_t)masterend, (uint64_t)masterstart); }
-    if (cons_file != NULL)
-    {
-      if ((fp = fopen(cons_file, "w")) == NULL) { fprintf(stderr, "Could not open input file %s\n", cons_file); exit(1); }
-      if (leftbp > 0) { fprintf(fp, ">left-extension %d bp\n", leftbp); write_wrapped(fp, master, (uint64_t)masterstart, (uint64_t)L, (uint64_t)masterstart); }
-      if (rightbp > 0) { fprintf(fp, ">right-extension %d bp\n", rightbp); write_wrapped(fp, master, (uint64_t)L + l, (uint64_t)masterend, (uint64_t)masterstart); }
-      fclose(fp);   /* the reference only closes it inside the right-extension branch (ram_extend.c:583) */
-      fp = NULL;
-    }
-    if (outtsv != NULL && (fp = fopen(outtsv, "w")) == NULL) { fprintf(stderr, "Could not create the TSV output file %s\n", outtsv); exit(1); }
-    if (outfa != NULL && (fp_fa = fopen(outfa, "w")) == NULL) { fprintf(stderr, "Could not create the FASTA output file %s\n", outfa); exit(1); }
+  struct coreAlignment **arr;
+  struct sequenceLibrary *lib;
+  int flanking;
+};
 
-    printf("\n\nExtended Sequences Report:\n");
-    printf("  *** Extended sequences are in 1-based, fully closed coordinates ***\n");
-    printf("SEQID  SEQSTART SEQEND ORIENT  EXTENSION_DETAILS\n");
-    long x = 0;
-    for (struct coreAlignment *s = cores; s != NULL; s = s->next, x++)
-    {
+static void results_rows(int lo_i, int hi_i, FILE **outs, void *user)
+{
+  const struct results_ctx *t = (const struct results_ctx *)user;
+  struct sequenceLibrary *lib = t->lib;
+  const int flanking = t->flanking;
+  FILE *out = outs[0], *fp = outs[1], *fp_fa = outs[2];
+  for (long x = lo_i; x < hi_i; x++)
+  {
+    struct coreAlignment *s = t->arr[x];
+
       const int si = s->seqIdx;
       const char *ident = lib->identifiers[si];
       const uint64_t lo = si > 0 ? lib->boundaries[si - 1] : 0;
@@ -328,7 +323,7 @@ static void write_results(const struct cli_opts *o, struct coreAlignment *cores,
       if (s->leftExtendable) snprintf(lbuf, sizeof(lbuf), "%d", s->leftExtensionLen); else strcpy(lbuf, "*");
       if (s->rightExtendable) snprintf(rbuf, sizeof(rbuf), "%d", s->rightExtensionLen); else strcpy(rbuf, "*");
 
-      printf("%s\t%ld\t%ld\t%c\tn=%ld,anchor_range=%ld-%ld,extended_left=%s,extended_right=%s,len=%d,score=%d",
+      fprintf(out, "%s\t%ld\t%ld\t%c\tn=%ld,anchor_range=%ld-%ld,extended_left=%s,extended_right=%s,len=%d,score=%d",
              ident, (long)(off + ext_start), (long)(off + ext_end), orient, x, (long)core_start, (long)core_end,
              lbuf, rbuf, ext_len, s->score);
       /* limit annotations, ram_extend.c:669-693 */
@@ -336,23 +331,23 @@ static void write_results(const struct cli_opts *o, struct coreAlignment *cores,
       {
         if (s->leftExtendable && ((s->leftSeqPos - (uint64_t)s->leftExtensionLen) - s->lowerSeqBound) < 20)
         {
-          if (s->lowerSeqBoundFlag == SEQ_BOUNDARY) printf(",leftSeqLimit");
-          else if (s->lowerSeqBoundFlag == L_BOUNDARY) printf(",leftExtLimit");
-          else if (s->lowerSeqBoundFlag == CORE_BOUNDARY) printf(",leftCoreLimit");
+          if (s->lowerSeqBoundFlag == SEQ_BOUNDARY) fprintf(out, ",leftSeqLimit");
+          else if (s->lowerSeqBoundFlag == L_BOUNDARY) fprintf(out, ",leftExtLimit");
+          else if (s->lowerSeqBoundFlag == CORE_BOUNDARY) fprintf(out, ",leftCoreLimit");
         }
         if (s->rightExtendable && (s->upperSeqBound - (s->rightSeqPos + (uint64_t)s->rightExtensionLen)) < 20)
         {
-          if (s->upperSeqBoundFlag == SEQ_BOUNDARY) printf(",rightSeqLimit");
-          else if (s->upperSeqBoundFlag == L_BOUNDARY) printf(",rightExtLimit");
-          else if (s->upperSeqBoundFlag == CORE_BOUNDARY) printf(",rightCoreLimit");
+          if (s->upperSeqBoundFlag == SEQ_BOUNDARY) fprintf(out, ",rightSeqLimit");
+          else if (s->upperSeqBoundFlag == L_BOUNDARY) fprintf(out, ",rightExtLimit");
+          else if (s->upperSeqBoundFlag == CORE_BOUNDARY) fprintf(out, ",rightCoreLimit");
         }
       }
       else
       {
-        if (s->leftExtendable && (s->upperSeqBound - (s->leftSeqPos + (uint64_t)s->leftExtensionLen)) < 20) printf(",leftCoreLimit");
-        if (s->rightExtendable && ((s->rightSeqPos - (uint64_t)s->rightExtensionLen) - s->lowerSeqBound) < 20) printf(",rightCoreLimit");
+        if (s->leftExtendable && (s->upperSeqBound - (s->leftSeqPos + (uint64_t)s->leftExtensionLen)) < 20) fprintf(out, ",leftCoreLimit");
+        if (s->rightExtendable && ((s->rightSeqPos - (uint64_t)s->rightExtensionLen) - s->lowerSeqBound) < 20) fprintf(out, ",rightCoreLimit");
       }
-      printf("\n");
+      fprintf(out, "\n");
 
       if (fp != NULL)   /* NB: anchor_range here is window-relative, without the genomic offset (ram_extend.c:696-712) */
         fprintf(fp, "%s\t%ld\t%ld\t%c\tn=%ld,anchor_range=%ld-%ld,extended_left=%s,extended_right=%s,len=%d,score=%d\n",
@@ -384,22 +379,71 @@ static void write_results(const struct cli_opts *o, struct coreAlignment *cores,
         {
           const size_t len = (size_t)(to - from + 1);
           char *buf = (char *)malloc(len + 1);
+          const char *codes = lib->sequence ? lib->sequence + from : NULL;
+          char *tmpc = NULL;
+          if (!codes)                   /* packed library: decode just this stretch */
+          {
+            tmpc = (char *)malloc(len + 1);
+            const ramx_packed_library *pl = ramx_packed_of(lib);
+            if (!pl || ramx_packed_decode(pl, from, len, tmpc) != RAMX_OK) { fprintf(stderr, "RAMExtend(ramx): cannot read %zu bases at %ld of the packed library\n", len, (long)from); exit(1); }
+            codes = tmpc;
+          }
           if (orient == '-')
-            for (uint64_t j = to;; j--) { buf[cnt++] = code_to_char(code_compl(lib->sequence[j])); if (j == from) break; }
+            for (size_t j = len; j-- > 0;) buf[cnt++] = code_to_char(code_compl(codes[j]));
           else
-            for (uint64_t j = from; j <= to; j++) buf[cnt++] = code_to_char(lib->sequence[j]);
+            for (size_t j = 0; j < len; j++) buf[cnt++] = code_to_char(codes[j]);
           fwrite(buf, 1, cnt, fp_fa);
-          free(buf);
+          free(buf); free(tmpc);
         }
         else if (orient == '-')
         {
           /* the reference's do/while emits one base even for an inverted interval */
-          fputc(code_to_char(code_compl(lib->sequence[to])), fp_fa);
+          fputc(code_to_char(code_compl(ramx_lib_code(lib, to))), fp_fa);
           cnt = 1;
         }
         fputc('\n', fp_fa);
         if (cnt == 0) { fprintf(stderr, "Error: No sequence emitted for %s:%ld-%ld_%c\n", ident, (long)from, (long)to, orient); exit(1); }
       }
+      }
+}
+
+/* consensus records, report table, -cons / -outtsv / -outfa: reference ram_extend.c:515-781 */
+static void write_results(const struct cli_opts *o, struct coreAlignment *cores, struct sequenceLibrary *lib, const char *master,
+                          int rightbp, int leftbp, const char *cons_file, const char *outtsv, const char *outfa)
+{
+  const int L = o->L, l = 1, flanking = o->flanking;
+  const long masterend = (long)L + l + rightbp;
+  const long masterstart = (long)L - leftbp;
+  if (rightbp > 0 || leftbp > 0)
+  {
+    FILE *fp = NULL, *fp_fa = NULL;
+    if (leftbp > 0) { printf(">left-extension\n"); write_wrapped(stdout, master, (uint64_t)masterstart, (uint64_t)L, (uint64_t)masterstart); }
+    if (rightbp > 0) { printf(">right-extension\n"); write_wrapped(stdout, master, (uint64_t)L + l, (uint64_t)masterend, (uint64_t)masterstart); }
+    if (cons_file != NULL)
+    {
+      if ((fp = fopen(cons_file, "w")) == NULL) { fprintf(stderr, "Could not open input file %s\n", cons_file); exit(1); }
+      if (leftbp > 0) { fprintf(fp, ">left-extension %d bp\n", leftbp); write_wrapped(fp, master, (uint64_t)masterstart, (uint64_t)L, (uint64_t)masterstart); }
+      if (rightbp > 0) { fprintf(fp, ">right-extension %d bp\n", rightbp); write_wrapped(fp, master, (uint64_t)L + l, (uint64_t)masterend, (uint64_t)masterstart); }
+      fclose(fp);   /* the reference only closes it inside the right-extension branch (ram_extend.c:583) */
+      fp = NULL;
+    }
+    if (outtsv != NULL && (fp = fopen(outtsv, "w")) == NULL) { fprintf(stderr, "Could not create the TSV output file %s\n", outtsv); exit(1); }
+    if (outfa != NULL && (fp_fa = fopen(outfa, "w")) == NULL) { fprintf(stderr, "Could not create the FASTA output file %s\n", outfa); exit(1); }
+
+    printf("\n\nExtended Sequences Report:\n");
+    printf("  *** Extended sequences are in 1-based, fully closed coordinates ***\n");
+    printf("SEQID  SEQSTART SEQEND ORIENT  EXTENSION_DETAILS\n");
+    {
+      int cnt = 0;
+      for (struct coreAlignment *s = cores; s != NULL; s = s->next) cnt++;
+      struct coreAlignment **arr = (struct coreAlignment **)malloc(sizeof(*arr) * (size_t)(cnt ? cnt : 1));
+      cnt = 0;
+      for (struct coreAlignment *s = cores; s != NULL; s = s->next) arr[cnt++] = s;
+      struct results_ctx ctx;
+      ctx.arr = arr; ctx.lib = lib; ctx.flanking = flanking;
+      FILE *outs[3] = { stdout, fp, fp_fa };
+      ramx_parallel_chunks(cnt, 3, outs, results_rows, &ctx);   /* formatted chunk by chunk on the host's cores, written in order */
+      free(arr);
     }
     if (fp != NULL) fclose(fp);
     if (fp_fa != NULL) fclose(fp_fa);
@@ -595,6 +639,7 @@ int ramx_cli_main(int argc, char **argv)
   struct cli_opts o;
   memset(&o, 0, sizeof(o));
   const int l = 1;
+  g_t_main = now_s();
 
   if (opt_bool(argc, argv, "-version"))
   {
@@ -660,6 +705,8 @@ int ramx_cli_main(int argc, char **argv)
 
   g_timing = getenv("RAMX_TIMING") != NULL;
   g_t_last = now_s();
+  if (g_timing) atexit(timing_at_exit);
+  phase_done("options");
   const int L = o.L;
   char *master = (char *)malloc((size_t)(2 * (long)L + l + 1));
   if (!master) { fprintf(stderr, "Could not allocate space for master array\n"); exit(1); }
@@ -667,7 +714,11 @@ int ramx_cli_main(int argc, char **argv)
 
   struct coreAlignment *cores = NULL;
   int N = 0;
-  struct sequenceLibrary *lib = ramx_load_sequence_subset_minimal(o.seq_file, o.ranges_file, &cores, &N, L + o.bandwidth);
+  /* the windows stay packed (4 bases per byte, as in the .2bit file) on the host and go to the device packed: the report and
+   * -outfa decode the few bases they print.  RAMX_CLI_BYTES=1: the one-byte-per-base library of the reference (A/B) */
+  struct sequenceLibrary *lib = getenv("RAMX_CLI_BYTES") != NULL
+                                    ? ramx_load_sequence_subset_minimal(o.seq_file, o.ranges_file, &cores, &N, L + o.bandwidth)
+                                    : ramx_load_sequence_subset_packed(o.seq_file, o.ranges_file, &cores, &N, L + o.bandwidth, NULL);
   FILE *fp_mat = NULL;
   if (o.outmat != NULL)       /* ram_extend.c:384-390 */
   {
@@ -705,5 +756,6 @@ int ramx_cli_main(int argc, char **argv)
   ramx_free_scoring_system(o.sp);
   ramx_free_library(lib, cores);
   free(master);
+  phase_done("free");
   return 0;
 }

@@ -90,6 +90,11 @@ struct ramx_dev
   int ordinal;
   hipStream_t stream;
   signed char *d_lib; unsigned long long lib_len; unsigned long long lib_cap;
+  // packed library (ramx_dev_load_library_packed): the .2bit payload of the windows + window / N-run tables; lib_packed = 1
+  int lib_packed;
+  unsigned char *d_pk_bytes, *d_pk_phase; unsigned long long *d_pk_wstart, *d_pk_wbyte, *d_pk_nstart; unsigned *d_pk_nlen;
+  size_t cap_pk_bytes, cap_pk_phase, cap_pk_wstart, cap_pk_wbyte, cap_pk_nstart, cap_pk_nlen, cap_flank_win;
+  int pk_windows, pk_nblocks; int *d_flank_win;
   // per direction
   ramx_flank *d_flanks; unsigned *d_bases; int2 *d_bounds; int4 *d_state[2]; int2 *d_trim;
   long long *d_sums; RamxCtl *d_ctl; signed char *d_cons;
@@ -176,6 +181,8 @@ extern "C" void ramx_dev_destroy(ramx_dev *d)
   // mappings of the other ranks' mailboxes (hipIpcOpenMemHandle): closed before anything of this device is released
   for (int q = 0; q < RAMX_MAX_RANKS; q++)
     if (d->peer_ipc[q]) { (void)hipIpcCloseMemHandle(d->peer_ipc[q]); d->peer_ipc[q] = NULL; }
+  (void)hipFree(d->d_pk_bytes); (void)hipFree(d->d_pk_phase); (void)hipFree(d->d_pk_wstart); (void)hipFree(d->d_pk_wbyte);
+  (void)hipFree(d->d_pk_nstart); (void)hipFree(d->d_pk_nlen); (void)hipFree(d->d_flank_win);
   (void)hipFree(d->d_lib); (void)hipFree(d->d_flanks); (void)hipFree(d->d_bases); (void)hipFree(d->d_bounds);
   (void)hipFree(d->d_state[0]); if (d->d_state[1] != d->d_state[0]) (void)hipFree(d->d_state[1]); (void)hipFree(d->d_trim); (void)hipFree(d->d_sums);
   (void)hipFree(d->d_ctl); (void)hipFree(d->d_cons); (void)hipFree(d->d_vote); (void)hipFree(d->d_err);
@@ -216,6 +223,69 @@ extern "C" int ramx_dev_load_library(ramx_dev *d, const int8_t *sequence, uint64
   if (length) HIPCHK(hipMemcpyAsync(d->d_lib, sequence, length, hipMemcpyHostToDevice, d->stream));
   HIPCHK(hipStreamSynchronize(d->stream));
   d->lib_len = length;
+  d->lib_packed = 0;
+  return RAMX_OK;
+}
+
+template <typename T>
+static int ensure(T **p, size_t *cap, size_t need_bytes);
+
+extern "C" int ramx_dev_load_library_packed(ramx_dev *d, const struct ramx_packed_library *pl)
+{
+  if (!d || !pl || pl->n_windows < 0 || (pl->n_windows && (!pl->win_start || !pl->win_byte || !pl->win_phase || !pl->bytes)) ||
+      pl->n_blocks < 0 || (pl->n_blocks && (!pl->n_start || !pl->n_len)))
+  { ramx_set_error("ramx_dev_load_library_packed: bad argument"); return RAMX_ERR_ARG; }
+  HIPCHK(hipSetDevice(d->ordinal));
+  const size_t nw = (size_t)pl->n_windows, nb = (size_t)pl->n_blocks;
+  int rc;
+  if ((rc = ensure(&d->d_pk_bytes, &d->cap_pk_bytes, (size_t)pl->n_bytes + 16))) return rc;
+  if ((rc = ensure(&d->d_pk_wstart, &d->cap_pk_wstart, (nw + 1) * sizeof(unsigned long long)))) return rc;
+  if ((rc = ensure(&d->d_pk_wbyte, &d->cap_pk_wbyte, (nw + 1) * sizeof(unsigned long long)))) return rc;
+  if ((rc = ensure(&d->d_pk_phase, &d->cap_pk_phase, nw + 1))) return rc;
+  if ((rc = ensure(&d->d_pk_nstart, &d->cap_pk_nstart, (nb + 1) * sizeof(unsigned long long)))) return rc;
+  if ((rc = ensure(&d->d_pk_nlen, &d->cap_pk_nlen, (nb + 1) * sizeof(unsigned)))) return rc;
+  if (pl->n_bytes) HIPCHK(hipMemcpyAsync(d->d_pk_bytes, pl->bytes, (size_t)pl->n_bytes, hipMemcpyHostToDevice, d->stream));
+  if (nw)
+  {
+    HIPCHK(hipMemcpyAsync(d->d_pk_wstart, pl->win_start, (nw + 1) * sizeof(unsigned long long), hipMemcpyHostToDevice, d->stream));
+    HIPCHK(hipMemcpyAsync(d->d_pk_wbyte, pl->win_byte, (nw + 1) * sizeof(unsigned long long), hipMemcpyHostToDevice, d->stream));
+    HIPCHK(hipMemcpyAsync(d->d_pk_phase, pl->win_phase, nw, hipMemcpyHostToDevice, d->stream));
+  }
+  if (nb)
+  {
+    HIPCHK(hipMemcpyAsync(d->d_pk_nstart, pl->n_start, nb * sizeof(unsigned long long), hipMemcpyHostToDevice, d->stream));
+    HIPCHK(hipMemcpyAsync(d->d_pk_nlen, pl->n_len, nb * sizeof(unsigned), hipMemcpyHostToDevice, d->stream));
+  }
+  HIPCHK(hipStreamSynchronize(d->stream));
+  d->lib_len = pl->length; d->pk_windows = pl->n_windows; d->pk_nblocks = pl->n_blocks;
+  d->lib_packed = 1;
+  return RAMX_OK;
+}
+
+// flank descriptors (already on the device) -> transposed, pre-oriented 4-bit windows + bounds, from either kind of library
+static int launch_pack(ramx_dev *d, int Nx, int Np, int KW, int W)
+{
+  dim3 grid((Np + 255) / 256, KW);
+  if (!d->lib_packed)
+  {
+    hipLaunchKernelGGL(ramx_pack_kernel, grid, dim3(256), 0, d->stream, d->d_lib, (unsigned long long)d->lib_len,
+                       d->d_flanks, Nx, Np, W, d->d_bases, d->d_bounds);
+    HIPCHK(hipGetLastError());
+    return RAMX_OK;
+  }
+  int rc;
+  if ((rc = ensure(&d->d_flank_win, &d->cap_flank_win, (size_t)Np * sizeof(int)))) return rc;
+  PkLib L;
+  L.bytes = d->d_pk_bytes; L.win_start = d->d_pk_wstart; L.win_byte = d->d_pk_wbyte; L.win_phase = d->d_pk_phase;
+  L.n_start = d->d_pk_nstart; L.n_len = d->d_pk_nlen; L.length = d->lib_len; L.n_windows = d->pk_windows; L.n_blocks = d->pk_nblocks;
+  if (Nx > 0)
+  {
+    hipLaunchKernelGGL(ramx_flank_window_kernel, dim3((Nx + 255) / 256), dim3(256), 0, d->stream, L, d->d_flanks, Nx, d->d_flank_win);
+    HIPCHK(hipGetLastError());
+  }
+  hipLaunchKernelGGL(ramx_pack2_kernel, dim3((Np + 255) / 256, (KW + RAMX_PK_WORDS - 1) / RAMX_PK_WORDS), dim3(256), 0, d->stream, L, d->d_flanks,
+                     d->d_flank_win, Nx, Np, W, KW, d->d_bases, d->d_bounds);
+  HIPCHK(hipGetLastError());
   return RAMX_OK;
 }
 
@@ -270,10 +340,7 @@ extern "C" int ramx_dev_begin_direction(ramx_dev *d, const ramx_flank *flanks, i
   }
   if ((rc = ensure(&d->d_cons, &d->cap_cons, (size_t)p->L + 16))) return rc;
   if (Nx) HIPCHK(hipMemcpyAsync(d->d_flanks, flanks, (size_t)Nx * sizeof(ramx_flank), hipMemcpyHostToDevice, d->stream));
-  dim3 grid((Np + 255) / 256, KW);
-  hipLaunchKernelGGL(ramx_pack_kernel, grid, dim3(256), 0, d->stream, d->d_lib, (unsigned long long)d->lib_len,
-                     d->d_flanks, Nx, Np, W, d->d_bases, d->d_bounds);
-  HIPCHK(hipGetLastError());
+  if ((rc = launch_pack(d, Nx, Np, KW, W)) != RAMX_OK) return rc;
   HIPCHK(hipMemsetAsync(d->d_sums, 0, 3 * NSHARD * 4 * sizeof(long long), d->stream));
   HIPCHK(hipMemsetAsync(d->d_cons, 0, (size_t)p->L + 16, d->stream));
   HIPCHK(hipStreamSynchronize(d->stream));
@@ -853,9 +920,7 @@ static int run_families_pass(ramx_dev *d, const ramx_flank *flanks, int32_t n_pa
   dfd = (FamDesc *)d->d_fam; dctl = d->d_famctl;
   FAMCHK(hipMemcpyAsync(dfd, hfd, sizeof(FamDesc) * n_families, hipMemcpyHostToDevice, d->stream));
   if (n_padded) FAMCHK(hipMemcpyAsync(d->d_flanks, flanks, (size_t)n_padded * sizeof(ramx_flank), hipMemcpyHostToDevice, d->stream));
-  hipLaunchKernelGGL(ramx_pack_kernel, dim3((Np + 255) / 256, KW), dim3(256), 0, d->stream, d->d_lib, (unsigned long long)d->lib_len,
-                     d->d_flanks, n_padded, Np, W, d->d_bases, d->d_bounds);
-  FAMCHK(hipGetLastError());
+  if ((rc = launch_pack(d, n_padded, Np, KW, W)) != RAMX_OK) goto done;
   FAMCHK(hipMemsetAsync(d->d_cons, 0, (size_t)n_families * (L > 0 ? L : 1) + 16, d->stream));   // columns a family never ran read as 0
   memset(&fa, 0, sizeof(fa));
   fa.bases = d->d_bases; fa.bounds = d->d_bounds; fa.fam = dfd; fa.trim = d->d_trim; fa.ctl_out = dctl; fa.cons_out = d->d_cons;

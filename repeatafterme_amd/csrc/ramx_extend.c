@@ -63,9 +63,24 @@ static uint64_t fingerprint(const int8_t *p, uint64_t n)
   return h ? h : 1;
 }
 
+/* the library the device holds came from a packed twin (ramx_preload_library_packed): the seqLib it belongs to */
+static const struct sequenceLibrary *g_packed_owner = NULL;
+
 void ramx_invalidate_library(void)
 {
-  g_lib_ptr = NULL; g_lib_len = 0; g_lib_fp = 0; g_lib_trusted = 0; g_bl_n = 0;
+  g_lib_ptr = NULL; g_lib_len = 0; g_lib_fp = 0; g_lib_trusted = 0; g_bl_n = 0; g_packed_owner = NULL;
+}
+
+int ramx_preload_library_packed(const struct sequenceLibrary *seqLib, const struct ramx_packed_library *pl)
+{
+  if (!seqLib || !pl) { ramx_set_error("ramx_preload_library_packed: bad argument"); return RAMX_ERR_ARG; }
+  ramx_dev *d = ramx_default_device();
+  if (!d) return RAMX_ERR_NO_DEVICE;
+  ramx_invalidate_library();
+  const int rc = ramx_dev_load_library_packed(d, pl);
+  if (rc != RAMX_OK) return rc;
+  g_packed_owner = seqLib;
+  return RAMX_OK;
 }
 
 int ramx_preload_library(const int8_t *sequence, uint64_t seq_len)
@@ -102,7 +117,8 @@ struct trace_ctx
   const int32_t *core_index;      /* flank -> position of its core in the list (the reference's n) */
   const ramx_flank *flanks;
   const ramx_flat_cores *cores;
-  const int8_t *sequence;
+  const int8_t *sequence;               /* one byte per base, or NULL: */
+  const ramx_packed_library *packed;    /* the packed twin */
 };
 static FILE *g_trace_file = NULL;
 
@@ -110,6 +126,14 @@ static char trace_num_to_char(int8_t z)      /* sequence.c:1091-1111 */
 {
   static const char t[8] = { 'A', 'C', 'G', 'T', 'a', 'c', 'g', 't' };
   return (z >= 0 && z < 8) ? t[z] : 'N';
+}
+
+static int8_t trace_code(const struct trace_ctx *t, uint64_t p)
+{
+  if (t->sequence) return t->sequence[p];
+  char c = RAMX_SYM_N;
+  if (t->packed) (void)ramx_packed_decode(t->packed, p, 1, &c);
+  return (int8_t)c;
 }
 
 static void trace_row(int32_t row, int32_t besta, const int8_t *codes, const int32_t *best_score, const int32_t *best_idx, void *user)
@@ -127,7 +151,7 @@ static void trace_row(int32_t row, int32_t besta, const int8_t *codes, const int
       const int64_t tt = (int64_t)(j - W) + row;
       const int64_t p = f->start + (int64_t)f->step * tt;
       char base = 'X';
-      if (p >= 0 && p >= t->cores->lower[n] && p <= t->cores->upper[n]) base = trace_num_to_char(t->sequence[p]);
+      if (p >= 0 && p >= t->cores->lower[n] && p <= t->cores->upper[n]) base = trace_num_to_char(trace_code(t, (uint64_t)p));
       const int c = codes[(size_t)i * B + j];
       path[j] = c == 0 ? base : (c == 1 ? '-' : (char)tolower((unsigned char)base));
     }
@@ -189,13 +213,14 @@ int ramx_resolve_flanks(int direction, const ramx_flat_cores *c, int bandwidth, 
   return nx;
 }
 
-int ramx_extend_flat(int direction, ramx_flat_cores *c, const int8_t *sequence, uint64_t seq_len,
-                     int8_t *master, const ramx_params *p, ramx_run_info *info)
+/* packed != NULL: the device already holds the library (ramx_preload_library_packed); `sequence` is not looked at */
+static int extend_flat_impl(int direction, ramx_flat_cores *c, const int8_t *sequence, uint64_t seq_len,
+                            int8_t *master, const ramx_params *p, ramx_run_info *info, const ramx_packed_library *packed)
 {
   ramx_run_info local;
   if (!info) info = &local;
   memset(info, 0, sizeof(*info));
-  if (!c || !p || !master || (c->n > 0 && !sequence)) { ramx_set_error("ramx_extend_flat: bad argument"); return RAMX_ERR_ARG; }
+  if (!c || !p || !master || (c->n > 0 && !sequence && !packed)) { ramx_set_error("ramx_extend_flat: bad argument"); return RAMX_ERR_ARG; }
   ramx_dev *d = ramx_default_device();
   if (!d) return RAMX_ERR_NO_DEVICE;
   const double t0 = wall_ms();
@@ -210,7 +235,7 @@ int ramx_extend_flat(int direction, ramx_flat_cores *c, const int8_t *sequence, 
   SEAM1_PHASE("resolve flanks");
   /* the library is shared by both directions: upload once per (pointer, length, content); nothing to upload when no
    * core is extendable in this direction */
-  if (nx > 0 && !(g_lib_trusted && sequence == g_lib_ptr && seq_len == g_lib_len))
+  if (!packed && nx > 0 && !(g_lib_trusted && sequence == g_lib_ptr && seq_len == g_lib_len))
   {
     const uint64_t fp = seq_len <= RAMX_FP_MAX ? fingerprint(sequence, seq_len) : 0;
     if (sequence != g_lib_ptr || seq_len != g_lib_len || fp == 0 || fp != g_lib_fp)
@@ -229,7 +254,7 @@ int ramx_extend_flat(int direction, ramx_flat_cores *c, const int8_t *sequence, 
   if (g_trace_file != NULL)
   {
     tctx.out = g_trace_file; tctx.direction = direction; tctx.W = W; tctx.nx = nx; tctx.core_index = map; tctx.flanks = fl;
-    tctx.cores = c; tctx.sequence = sequence;
+    tctx.cores = c; tctx.sequence = sequence; tctx.packed = packed;
     ramx_dev_set_row_trace(d, trace_row, &tctx);
   }
   if (g_trace_file == NULL && nx > 0 && nx <= ramx_dev_family_route_max(d, p) && L > 0 && W >= 1 && getenv("RAMX_NO_FAMILY_ROUTE") == NULL)
@@ -284,6 +309,12 @@ int ramx_extend_flat(int direction, ramx_flat_cores *c, const int8_t *sequence, 
 #undef SEAM1_PHASE
   free(cons); free(th); free(tp); free(map); free(fl);
   return rc == RAMX_OK ? info->ret : rc;
+}
+
+int ramx_extend_flat(int direction, ramx_flat_cores *c, const int8_t *sequence, uint64_t seq_len,
+                     int8_t *master, const ramx_params *p, ramx_run_info *info)
+{
+  return extend_flat_impl(direction, c, sequence, seq_len, master, p, info, NULL);
 }
 
 int ramx_extend_alignment(int direction, struct coreAlignment *coreAlign, int ****score,
@@ -341,7 +372,20 @@ int ramx_extend_alignment(int direction, struct coreAlignment *coreAlign, int **
   p.when_to_stop = g_when_to_stop; p.l = g_l; p.gapopen = scoreParams->gapopen; p.gapextn = scoreParams->gapextn;
   p.matrix = mflat;
   ramx_run_info info;
-  int ret = ramx_extend_flat(direction, &fc, (const int8_t *)seqLib->sequence, seqLib->length, (int8_t *)master, &p, &info);
+  /* a library that was loaded packed (ramx_load_sequence_subset_packed: ->sequence is NULL) runs from its packed twin, which
+   * goes to the device now unless ramx_preload_library_packed has put it there already */
+  const ramx_packed_library *packed = NULL;
+  if (seqLib->sequence == NULL && fc.n > 0)
+  {
+    packed = ramx_packed_of(seqLib);
+    if (!packed) { fprintf(stderr, "RAMExtend(ramx): the sequence library holds no bases (sequence == NULL and no packed twin)\n"); exit(1); }
+    if (g_packed_owner != seqLib && ramx_preload_library_packed(seqLib, packed) != RAMX_OK)
+    {
+      fprintf(stderr, "RAMExtend(ramx): device extension failed: %s\n", ramx_last_error());
+      exit(1);
+    }
+  }
+  int ret = extend_flat_impl(direction, &fc, (const int8_t *)seqLib->sequence, seqLib->length, (int8_t *)master, &p, &info, packed);
   if (ret < 0)
   {
     /* the reference has no error return on this path: print + exit(1) like its other failures */
@@ -448,7 +492,7 @@ int ramx_extend_batch(int direction, ramx_family *fam, int32_t F, const ramx_par
     int32_t *tp = (int32_t *)malloc(sizeof(int32_t) * (fpos ? fpos : 1));
     if (!lib_cached)
     {
-      g_lib_ptr = NULL; g_lib_len = 0; g_lib_fp = 0; g_lib_trusted = 0; /* whatever library the device held is replaced */
+      g_lib_ptr = NULL; g_lib_len = 0; g_lib_fp = 0; g_lib_trusted = 0; g_packed_owner = NULL; /* whatever library the device held is replaced */
       rc = ramx_dev_load_library(d, lib, total_len);
       if (rc == RAMX_OK)
       {

@@ -86,6 +86,93 @@ __global__ void ramx_pack_kernel(const signed char *__restrict__ lib, unsigned l
     bounds[n] = make_int2(1, 0);   // empty interval: every cell out of bounds
   bases[(size_t)k * Np + n] = word;
 }
+
+// ------------------------------------------------------------------------------------------
+// the same windows built straight from the .2bit payload (include/ramx.h ramx_packed_library): four bases per
+// byte, first base in the most significant bits, T C A G = 0 1 2 3 (kentsrc/twoBitNew.c:531-594, dnautil.h:23-27); runs of N
+// (:597-613) as sorted (start, length) pairs in library coordinates.  The one-byte-per-base library never exists.
+// ------------------------------------------------------------------------------------------
+struct PkLib
+{
+  const unsigned char *bytes;
+  const unsigned long long *win_start, *win_byte;   // [n_windows + 1]
+  const unsigned char *win_phase;
+  const unsigned long long *n_start;
+  const unsigned *n_len;
+  unsigned long long length;
+  int n_windows, n_blocks;
+};
+
+__device__ __forceinline__ int pk_window_of(const PkLib &L, unsigned long long p)     // last window that starts at or before p
+{
+  int lo = 0, hi = L.n_windows;
+  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (L.win_start[mid] <= p) lo = mid; else hi = mid; }
+  return lo;
+}
+
+// window of every flank's first base (its other bases lie in the same window unless the caller's bounds say otherwise:
+// ramx_pack2_kernel looks again for those)
+__global__ void ramx_flank_window_kernel(const PkLib L, const ramx_flank *__restrict__ fl, int Nx, int *__restrict__ flank_win)
+{
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= Nx) return;
+  const ramx_flank f = fl[n];
+  long long p = f.start + (long long)f.step * (f.t_lo > 0 ? f.t_lo : 0);
+  if (p < 0) p = 0;
+  if ((unsigned long long)p >= L.length) p = L.length ? (long long)L.length - 1 : 0;
+  flank_win[n] = L.n_windows > 0 ? pk_window_of(L, (unsigned long long)p) : 0;
+}
+
+#define RAMX_PK_WORDS 32
+__global__ void ramx_pack2_kernel(const PkLib L, const ramx_flank *__restrict__ fl, const int *__restrict__ flank_win, int Nx, int Np, int W, int KW,
+                                  unsigned *__restrict__ bases, int2 *__restrict__ bounds)
+{
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= Np) return;
+  // RAMX_PK_WORDS consecutive words (8 bases each) of one flank per thread: 256 bases are ONE 64-byte line of the payload, so a
+  // thread's loads stay in the line it has just brought in (one word per thread, as in ramx_pack_kernel, touches 64 different
+  // lines per wavefront for 2-3 bytes each)
+  for (int k = blockIdx.y * RAMX_PK_WORDS; k < (int)(blockIdx.y + 1) * RAMX_PK_WORDS && k < KW; k++)
+  {
+  unsigned word = 0x88888888u;   // class 8 = N everywhere
+  if (n < Nx)
+  {
+    const ramx_flank f = fl[n];
+    int w = flank_win[n];
+    word = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+    {
+      const int t = 8 * k + i - W - 8;   // one leading pad word: nibble index t'' = t + W + 8
+      unsigned c = 8;
+      if (t >= f.t_lo && t <= f.t_hi)
+      {
+        const long long p = f.start + (long long)f.step * t;
+        if (p >= 0 && (unsigned long long)p < L.length)
+        {
+          const unsigned long long up = (unsigned long long)p;
+          if (up < L.win_start[w] || up >= L.win_start[w + 1]) w = pk_window_of(L, up);
+          const unsigned long long q = up - L.win_start[w] + L.win_phase[w];
+          const unsigned v = (L.bytes[L.win_byte[w] + (q >> 2)] >> (6 - 2 * (unsigned)(q & 3))) & 3u;
+          c = (0x2013u >> (4 * v)) & 0xfu;                        // T C A G -> 3 1 0 2 (sequence.h:7-15)
+          if (L.n_blocks > 0)
+          {
+            int a = -1, z = L.n_blocks;                            // last run that starts at or before p
+            while (z - a > 1) { const int mid = (a + z) >> 1; if (L.n_start[mid] <= up) a = mid; else z = mid; }
+            if (a >= 0 && up < L.n_start[a] + L.n_len[a]) c = 8;
+          }
+          if (c < 4 && f.compl_) c = 3 - c;
+        }
+      }
+      word |= c << (4 * i);
+    }
+    if (k == 0) bounds[n] = make_int2(f.t_lo + W, f.t_hi + W);
+  }
+  else if (k == 0)
+    bounds[n] = make_int2(1, 0);   // empty interval: every cell out of bounds
+  bases[(size_t)k * Np + n] = word;
+  }
+}
 #endif
 
 // ------------------------------------------------------------------------------------------

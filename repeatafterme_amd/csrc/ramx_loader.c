@@ -17,6 +17,8 @@
  */
 #include <ctype.h>
 #include <pthread.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <stdlib.h>
 #include <unistd.h>
 #include <stdio.h>
@@ -47,11 +49,8 @@ struct tb_file
   int swapped, version;
   uint32_t seq_count;
   struct tb_index *index;       /* sorted by name for bsearch */
-  /* header of the most recently used record (ranges arrive sorted by name) */
-  const struct tb_index *cur;
-  uint32_t size, n_count;
-  uint32_t *n_start, *n_size;
-  uint64_t dna_offset;
+  const unsigned char *map;     /* the whole file, mapped read-only */
+  uint64_t map_len;
 };
 
 static uint32_t bswap32(uint32_t v) { return (v >> 24) | ((v >> 8) & 0xff00u) | ((v << 8) & 0xff0000u) | (v << 24); }
@@ -111,42 +110,24 @@ static struct tb_file *tb_open(const char *path)
     t->index[i].offset = (t->version == 1) ? rd64(t) : rd32(t);
   }
   qsort(t->index, t->seq_count, sizeof(struct tb_index), idx_cmp);
+  {
+    struct stat st;
+    if (fstat(fileno(t->f), &st) != 0 || st.st_size <= 0) die255("%s is truncated", path, 0, 0);
+    t->map_len = (uint64_t)st.st_size;
+    void *m = mmap(NULL, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fileno(t->f), 0);
+    if (m == MAP_FAILED) die255("cannot map %s", path, 0, 0);
+    t->map = (const unsigned char *)m;
+  }
   return t;
 }
 
 static void tb_close(struct tb_file *t)
 {
   for (uint32_t i = 0; i < t->seq_count; i++) free(t->index[i].name);
-  free(t->index); free(t->n_start); free(t->n_size);
+  free(t->index);
+  if (t->map) munmap((void *)t->map, (size_t)t->map_len);
   fclose(t->f);
   free(t);
-}
-
-/* position on a record and cache its header (size, N blocks, where the packed DNA starts) */
-static void tb_select(struct tb_file *t, const char *name)
-{
-  if (t->cur && strcmp(t->cur->name, name) == 0) return;
-  struct tb_index key;
-  key.name = (char *)name;
-  const struct tb_index *ix = (const struct tb_index *)bsearch(&key, t->index, t->seq_count, sizeof(key), idx_cmp);
-  if (!ix)
-  {
-    fflush(stdout);
-    fprintf(stderr, "%s is not in %s\n", name, t->path);
-    exit(255);
-  }
-  fseeko(t->f, (off_t)ix->offset, SEEK_SET);
-  t->size = rd32(t);
-  t->n_count = rd32(t);
-  free(t->n_start); free(t->n_size);
-  t->n_start = (uint32_t *)malloc(sizeof(uint32_t) * (t->n_count ? t->n_count : 1));
-  t->n_size = (uint32_t *)malloc(sizeof(uint32_t) * (t->n_count ? t->n_count : 1));
-  for (uint32_t i = 0; i < t->n_count; i++) t->n_start[i] = rd32(t);
-  for (uint32_t i = 0; i < t->n_count; i++) t->n_size[i] = rd32(t);
-  uint32_t mask_count = rd32(t);
-  fseeko(t->f, (off_t)mask_count * 8 + 4, SEEK_CUR);   /* soft-mask blocks + reserved word: case is discarded */
-  t->dna_offset = (uint64_t)ftello(t->f);
-  t->cur = ix;
 }
 
 struct nblocks { uint32_t count; uint32_t *start, *size; struct nblocks *next_alloc; };
@@ -159,11 +140,13 @@ struct window
   const struct nblocks *nb;         /* N blocks of that record (shared by the windows of the record) */
 };
 
-/* decode [start,end) of a record straight into reference base codes.  Thread-safe: pread on the descriptor, a
+/* decode [start,end) of a record straight into reference base codes.  Thread-safe: reads the mapped file, a
  * 256-entry table turns one packed byte into four codes (2bit: T=0 C=1 A=2 G=3, kentsrc/dnautil.h:23-27). */
 static uint32_t g_quad[256];
 static void quad_init(void)
 {
+  static int done = 0;
+  if (__atomic_load_n(&done, __ATOMIC_ACQUIRE)) return;
   static const unsigned char val_to_code[4] = { 3, 1, 0, 2 };
   for (int b = 0; b < 256; b++)
   {
@@ -171,28 +154,15 @@ static void quad_init(void)
     for (int k = 0; k < 4; k++) q[k] = val_to_code[(b >> (6 - 2 * k)) & 3];
     memcpy(&g_quad[b], q, 4);
   }
+  __atomic_store_n(&done, 1, __ATOMIC_RELEASE);
 }
 
-static int tb_decode(int fd, const char *path, uint64_t dna_offset, const struct nblocks *nb, int start, int end, char *out,
-                     unsigned char **scratch, size_t *scratch_cap)
+static int tb_decode(const unsigned char *map, uint64_t map_len, uint64_t dna_offset, const struct nblocks *nb, int start, int end, char *out)
 {
   const int p0 = start >> 2, p1 = (end + 3) >> 2;
   const size_t nbytes = (size_t)(p1 - p0);
-  if (nbytes > *scratch_cap)
-  {
-    free(*scratch);
-    *scratch_cap = nbytes + (nbytes >> 2) + 64;
-    *scratch = (unsigned char *)malloc(*scratch_cap);
-  }
-  unsigned char *packed = *scratch;
-  size_t got = 0;
-  while (got < nbytes)
-  {
-    ssize_t k = pread(fd, packed + got, nbytes - got, (off_t)(dna_offset + (uint64_t)p0 + got));
-    if (k <= 0) return -1;
-    got += (size_t)k;
-  }
-  (void)path;
+  if (dna_offset + (uint64_t)p0 > map_len || nbytes > map_len - (dna_offset + (uint64_t)p0)) return -1;
+  const unsigned char *packed = map + dna_offset + (uint64_t)p0;
   int i = start;
   /* head: up to the next multiple of four */
   for (; i < end && (i & 3); i++)
@@ -220,30 +190,6 @@ static int tb_decode(int fd, const char *path, uint64_t dna_offset, const struct
     if (s0 < e0) memset(out + (s0 - start), RAMX_SYM_N, (size_t)(e0 - s0));
   }
   return 0;
-}
-
-struct decode_job
-{
-  int fd;
-  const char *path;
-  const struct window *win;
-  const uint64_t *at;               /* start of window i in lib->sequence */
-  char *sequence;
-  int lo, hi;                       /* windows [lo, hi) */
-  int failed;
-};
-
-static void *decode_worker(void *arg)
-{
-  struct decode_job *j = (struct decode_job *)arg;
-  unsigned char *scratch = NULL;
-  size_t cap = 0;
-  for (int i = j->lo; i < j->hi && !j->failed; i++)
-    if (tb_decode(j->fd, j->path, j->win[i].dna_offset, j->win[i].nb, j->win[i].flank_start, j->win[i].flank_end,
-                  j->sequence + j->at[i], &scratch, &cap) != 0)
-      j->failed = 1;
-  free(scratch);
-  return NULL;
 }
 
 /* ------------------------------------------------------------------ BED-6 ranges */
@@ -427,9 +373,121 @@ static double ld_now(void)
 }
 #define LD_PHASE(name) do { if (timing) { const double t_ = ld_now(); fprintf(stderr, "RAMX_TIMING   loader: %-14s %9.3f ms\n", name, t_ - t_last); t_last = t_; } } while (0)
 
-struct sequenceLibrary *ramx_load_sequence_subset_minimal(const char *twoBitName, const char *rangeBEDName,
-                                                          struct coreAlignment **core_align, int *num_cores,
-                                                          int max_flanking_bp)
+/* ---- record headers, read by worker threads (pread: no shared file position) ---------------------------------------- */
+struct rec_hdr
+{
+  uint64_t offset;                  /* of the record in the file (from the index) */
+  uint32_t size;
+  struct nblocks nb;
+  uint64_t dna_offset;
+  int failed;
+};
+struct hdr_job { const unsigned char *map; uint64_t map_len; int swapped; struct rec_hdr *rec; int lo, hi; };
+
+/* n bytes at `off` of the mapped file (the mapping replaces a pread per record: 100,000 records are 300,000 system calls) */
+static int map_read(const unsigned char *map, uint64_t map_len, void *buf, size_t n, uint64_t off)
+{
+  if (off > map_len || n > map_len - off) return -1;
+  memcpy(buf, map + off, n);
+  return 0;
+}
+
+/* kentsrc/twoBitNew.c:369-397: dnaSize, nBlockCount, nStarts[], nSizes[], maskBlockCount, maskStarts[], maskSizes[], reserved, DNA */
+static void *hdr_worker(void *arg)
+{
+  struct hdr_job *j = (struct hdr_job *)arg;
+  for (int i = j->lo; i < j->hi; i++)
+  {
+    struct rec_hdr *r = &j->rec[i];
+    uint32_t h[2];
+    if (map_read(j->map, j->map_len, h, 8, r->offset) != 0) { r->failed = 1; continue; }
+    r->size = j->swapped ? bswap32(h[0]) : h[0];
+    r->nb.count = j->swapped ? bswap32(h[1]) : h[1];
+    const size_t nbn = r->nb.count;
+    r->nb.start = (uint32_t *)malloc(sizeof(uint32_t) * (nbn ? nbn : 1));
+    r->nb.size = (uint32_t *)malloc(sizeof(uint32_t) * (nbn ? nbn : 1));
+    if (nbn && (map_read(j->map, j->map_len, r->nb.start, 4 * nbn, r->offset + 8) != 0 ||
+                map_read(j->map, j->map_len, r->nb.size, 4 * nbn, r->offset + 8 + 4 * nbn) != 0)) { r->failed = 1; continue; }
+    if (j->swapped) for (size_t k = 0; k < nbn; k++) { r->nb.start[k] = bswap32(r->nb.start[k]); r->nb.size[k] = bswap32(r->nb.size[k]); }
+    uint32_t mc;
+    if (map_read(j->map, j->map_len, &mc, 4, r->offset + 8 + 8 * nbn) != 0) { r->failed = 1; continue; }
+    if (j->swapped) mc = bswap32(mc);
+    r->dna_offset = r->offset + 8 + 8 * nbn + 4 + 8 * (uint64_t)mc + 4;   /* soft-mask blocks + reserved word: case is discarded */
+  }
+  return NULL;
+}
+
+static int loader_threads(uint64_t work_items, uint64_t per_thread_min)
+{
+  int nthreads = 1;
+  const char *env = getenv("RAMX_LOADER_THREADS");
+  if (env) nthreads = atoi(env);
+  else if (work_items >= per_thread_min)
+  {
+    long c = sysconf(_SC_NPROCESSORS_ONLN);
+    nthreads = c > 16 ? 16 : (int)c;
+  }
+  if (nthreads < 1) nthreads = 1;
+  return nthreads;
+}
+
+/* ---- the windows' packed payload and / or their 1-byte decoding, by worker threads ------------------------------------- */
+struct fill_job
+{
+  const unsigned char *map; uint64_t map_len;
+  const struct window *win;
+  const uint64_t *at;               /* start of window i in library coordinates (= in lib->sequence) */
+  const uint64_t *byte_at;          /* start of window i's packed bytes in `packed` */
+  char *sequence;                   /* NULL: no 1-byte decoding */
+  unsigned char *packed;            /* NULL: packed payload not kept */
+  int lo, hi;                       /* windows [lo, hi) */
+  int failed;
+};
+
+static void *fill_worker(void *arg)
+{
+  struct fill_job *j = (struct fill_job *)arg;
+  for (int i = j->lo; i < j->hi && !j->failed; i++)
+  {
+    const struct window *w = &j->win[i];
+    if (j->packed)
+    {
+      /* the window's bytes of the record's packed DNA, as they are in the file (kentsrc/twoBitNew.c:531-594) */
+      const int p0 = w->flank_start >> 2, p1 = (w->flank_end + 3) >> 2;
+      if (map_read(j->map, j->map_len, j->packed + j->byte_at[i], (size_t)(p1 - p0), w->dna_offset + (uint64_t)p0) != 0) { j->failed = 1; break; }
+    }
+    if (j->sequence && tb_decode(j->map, j->map_len, w->dna_offset, w->nb, w->flank_start, w->flank_end, j->sequence + j->at[i]) != 0)
+      j->failed = 1;
+  }
+  return NULL;
+}
+
+/* registry: libraries of this loader that carry a packed twin (ramx_packed_of) */
+#define RAMX_MAX_PACKED 64
+static struct { const struct sequenceLibrary *lib; ramx_packed_library *pl; } g_packed[RAMX_MAX_PACKED];
+static pthread_mutex_t g_packed_mu = PTHREAD_MUTEX_INITIALIZER;
+static unsigned g_packed_gen = 1;       /* bumped whenever a twin is registered or released: invalidates ramx_lib_code's caches */
+
+const ramx_packed_library *ramx_packed_of(const struct sequenceLibrary *lib)
+{
+  const ramx_packed_library *r = NULL;
+  pthread_mutex_lock(&g_packed_mu);
+  for (int i = 0; i < RAMX_MAX_PACKED; i++) if (g_packed[i].lib == lib && lib != NULL) { r = g_packed[i].pl; break; }
+  pthread_mutex_unlock(&g_packed_mu);
+  return r;
+}
+
+static void packed_free(ramx_packed_library *pl)
+{
+  if (!pl) return;
+  free((void *)pl->win_start); free((void *)pl->win_byte); free((void *)pl->win_phase); free((void *)pl->bytes);
+  free((void *)pl->n_start); free((void *)pl->n_len);
+  free(pl);
+}
+
+/* mode bit 0: 1-byte lib->sequence (the reference's data model); bit 1: packed twin, registered for ramx_packed_of */
+static struct sequenceLibrary *load_subset(const char *twoBitName, const char *rangeBEDName, struct coreAlignment **core_align,
+                                           int *num_cores, int max_flanking_bp, int mode)
 {
   const int timing = getenv("RAMX_TIMING") != NULL;
   double t_last = timing ? ld_now() : 0;
@@ -445,59 +503,113 @@ struct sequenceLibrary *ramx_load_sequence_subset_minimal(const char *twoBitName
   free(tmp);
   LD_PHASE("sort");
 
+  /* the records the ranges name, in range order (sorted by name: equal names are neighbours); a name that is not in the
+   * file ends the run at the first range that uses it, as the reference's twoBitSeqSize does */
+  int *rec_of = (int *)malloc(sizeof(int) * (size_t)(n ? n : 1));
+  struct rec_hdr *rec = (struct rec_hdr *)calloc((size_t)(n ? n : 1), sizeof(*rec));
+  int nrec = 0;
+  for (int i = 0; i < n; i++)
+  {
+    if (i > 0 && strcmp(order[i]->name, order[i - 1]->name) == 0) { rec_of[i] = nrec - 1; continue; }
+    struct tb_index key;
+    key.name = order[i]->name;
+    const struct tb_index *ix = (const struct tb_index *)bsearch(&key, tb->index, tb->seq_count, sizeof(key), idx_cmp);
+    if (!ix)
+    {
+      fflush(stdout);
+      fprintf(stderr, "%s is not in %s\n", order[i]->name, tb->path);
+      exit(255);
+    }
+    rec[nrec].offset = ix->offset;
+    rec_of[i] = nrec++;
+  }
+  {
+    int nthreads = loader_threads((uint64_t)nrec, 2048);
+    if (nthreads > nrec) nthreads = nrec > 0 ? nrec : 1;
+    struct hdr_job *jobs = (struct hdr_job *)calloc((size_t)nthreads, sizeof(*jobs));
+    pthread_t *tid = (pthread_t *)calloc((size_t)nthreads, sizeof(*tid));
+    for (int t = 0; t < nthreads; t++)
+    {
+      jobs[t].map = tb->map; jobs[t].map_len = tb->map_len; jobs[t].swapped = tb->swapped; jobs[t].rec = rec;
+      jobs[t].lo = (int)((long long)nrec * t / nthreads); jobs[t].hi = (int)((long long)nrec * (t + 1) / nthreads);
+    }
+    for (int t = 1; t < nthreads; t++)
+      if (pthread_create(&tid[t], NULL, hdr_worker, &jobs[t]) != 0) { hdr_worker(&jobs[t]); tid[t] = 0; }
+    hdr_worker(&jobs[0]);
+    for (int t = 1; t < nthreads; t++) if (tid[t]) pthread_join(tid[t], NULL);
+    free(jobs); free(tid);
+    for (int k = 0; k < nrec; k++) if (rec[k].failed) die255("%s is truncated", tb->path, 0, 0);
+  }
+  LD_PHASE("record headers");
+
   struct window *win = (struct window *)malloc(sizeof(*win) * (size_t)(n ? n : 1));
-  uint64_t *at_of = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)(n ? n : 1));
-  struct nblocks *nb_list = NULL;
-  const struct tb_index *nb_for = NULL;
-  uint64_t total = 0;
+  uint64_t *at_of = (uint64_t *)malloc(sizeof(uint64_t) * ((size_t)n + 1));
+  uint64_t *byte_of = (uint64_t *)malloc(sizeof(uint64_t) * ((size_t)n + 1));
+  uint64_t total = 0, total_bytes = 0, n_runs = 0;
   for (int i = 0; i < n; i++)
   {
     const struct range *s = order[i];
-    tb_select(tb, s->name);
-    if (nb_for != tb->cur)          /* the N blocks of this record, kept for the decoding threads */
-    {
-      struct nblocks *nb = (struct nblocks *)malloc(sizeof(*nb));
-      nb->count = tb->n_count;
-      nb->start = (uint32_t *)malloc(sizeof(uint32_t) * (tb->n_count ? tb->n_count : 1));
-      nb->size = (uint32_t *)malloc(sizeof(uint32_t) * (tb->n_count ? tb->n_count : 1));
-      memcpy(nb->start, tb->n_start, sizeof(uint32_t) * tb->n_count);
-      memcpy(nb->size, tb->n_size, sizeof(uint32_t) * tb->n_count);
-      nb->next_alloc = nb_list;
-      nb_list = nb;
-      nb_for = tb->cur;
-    }
-    win[i].dna_offset = tb->dna_offset;
-    win[i].nb = nb_list;
+    const struct rec_hdr *r = &rec[rec_of[i]];
+    win[i].dna_offset = r->dna_offset;
+    win[i].nb = &r->nb;
     at_of[i] = total;
-    plan_window(s, i ? order[i - 1] : NULL, i + 1 < n ? order[i + 1] : NULL, (int)tb->size, max_flanking_bp, &win[i]);
-    if ((uint32_t)win[i].flank_end > tb->size)
-      die255("twoBitReadSeqFrag in %s end (%ld) >= seqSize (%ld)", s->name, win[i].flank_end, tb->size);
+    byte_of[i] = total_bytes;
+    plan_window(s, i ? order[i - 1] : NULL, i + 1 < n ? order[i + 1] : NULL, (int)r->size, max_flanking_bp, &win[i]);
+    if ((uint32_t)win[i].flank_end > r->size)
+      die255("twoBitReadSeqFrag in %s end (%ld) >= seqSize (%ld)", s->name, win[i].flank_end, r->size);
     if (win[i].flank_end - win[i].flank_start < 1)
       die255("twoBitReadSeqFrag in %s start (%ld) >= end (%ld)", s->name, win[i].flank_start, win[i].flank_end);
     total += (uint64_t)(win[i].flank_end - win[i].flank_start);
+    total_bytes += (uint64_t)(((win[i].flank_end + 3) >> 2) - (win[i].flank_start >> 2));
+    for (uint32_t k = 0; k < r->nb.count; k++)      /* N runs that touch the window (twoBitNew.c:597-613) */
+    {
+      const long s0 = r->nb.start[k], e0 = s0 + r->nb.size[k];
+      if (s0 >= win[i].flank_end) break;
+      if (e0 > win[i].flank_start) n_runs++;
+    }
   }
-
+  at_of[n] = total;
+  byte_of[n] = total_bytes;
   LD_PHASE("plan windows");
+
   struct sequenceLibrary *lib = (struct sequenceLibrary *)calloc(1, sizeof(*lib));
-  lib->sequence = (char *)malloc(total + 1);
+  lib->sequence = (mode & 1) ? (char *)malloc(total + 1) : NULL;
   lib->identifiers = (char **)calloc((size_t)n + 1, sizeof(char *));
   lib->boundaries = (uint64_t *)calloc((size_t)n + 1, sizeof(uint64_t));
   lib->offsets = (uint64_t *)calloc((size_t)n + 1, sizeof(uint64_t));
   struct coreAlignment *cores = (struct coreAlignment *)calloc((size_t)(n ? n : 1), sizeof(*cores));
-  /* decode every window: independent reads (pread) and writes, split over the host cores by bases */
+  ramx_packed_library *pl = NULL;
+  unsigned char *packed = NULL;
+  if (mode & 2)
+  {
+    pl = (ramx_packed_library *)calloc(1, sizeof(*pl));
+    packed = (unsigned char *)malloc(total_bytes + 16);
+    uint8_t *phase = (uint8_t *)malloc((size_t)n + 1);
+    uint64_t *ns = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)(n_runs + 1));
+    uint32_t *nl = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(n_runs + 1));
+    uint64_t q = 0;
+    for (int i = 0; i < n; i++)
+    {
+      phase[i] = (uint8_t)(win[i].flank_start & 3);
+      const struct nblocks *nb = win[i].nb;
+      for (uint32_t k = 0; k < nb->count; k++)      /* clipped to the window, in library coordinates (sorted: windows are) */
+      {
+        long s0 = nb->start[k], e0 = s0 + nb->size[k];
+        if (s0 >= win[i].flank_end) break;
+        if (s0 < win[i].flank_start) s0 = win[i].flank_start;
+        if (e0 > win[i].flank_end) e0 = win[i].flank_end;
+        if (s0 < e0) { ns[q] = at_of[i] + (uint64_t)(s0 - win[i].flank_start); nl[q] = (uint32_t)(e0 - s0); q++; }
+      }
+    }
+    pl->length = total; pl->n_windows = n; pl->win_start = at_of; pl->win_byte = byte_of; pl->win_phase = phase;
+    pl->bytes = packed; pl->n_bytes = total_bytes; pl->n_start = ns; pl->n_len = nl; pl->n_blocks = (int32_t)q;
+  }
+  /* every window: independent reads (pread) and writes, split over the host cores by bases */
   {
     quad_init();
-    int nthreads = 1;
-    const char *env = getenv("RAMX_LOADER_THREADS");
-    if (env) nthreads = atoi(env);
-    else if (total >= (8u << 20))
-    {
-      long c = sysconf(_SC_NPROCESSORS_ONLN);
-      nthreads = c > 16 ? 16 : (int)c;
-    }
-    if (nthreads < 1) nthreads = 1;
+    int nthreads = loader_threads(total, 8u << 20);
     if (nthreads > n) nthreads = n > 0 ? n : 1;
-    struct decode_job *jobs = (struct decode_job *)calloc((size_t)nthreads, sizeof(*jobs));
+    struct fill_job *jobs = (struct fill_job *)calloc((size_t)nthreads, sizeof(*jobs));
     pthread_t *tid = (pthread_t *)calloc((size_t)nthreads, sizeof(*tid));
     int lo = 0;
     for (int t = 0; t < nthreads; t++)
@@ -506,13 +618,13 @@ struct sequenceLibrary *ramx_load_sequence_subset_minimal(const char *twoBitName
       const uint64_t goal = total / (uint64_t)nthreads * (uint64_t)(t + 1);
       int hi = lo;
       while (hi < n && (t == nthreads - 1 || at_of[hi] < goal)) hi++;
-      jobs[t].fd = fileno(tb->f); jobs[t].path = tb->path; jobs[t].win = win; jobs[t].at = at_of;
-      jobs[t].sequence = lib->sequence; jobs[t].lo = lo; jobs[t].hi = hi; jobs[t].failed = 0;
+      jobs[t].map = tb->map; jobs[t].map_len = tb->map_len; jobs[t].win = win; jobs[t].at = at_of; jobs[t].byte_at = byte_of;
+      jobs[t].sequence = lib->sequence; jobs[t].packed = packed; jobs[t].lo = lo; jobs[t].hi = hi; jobs[t].failed = 0;
       lo = hi;
     }
     for (int t = 1; t < nthreads; t++)
-      if (pthread_create(&tid[t], NULL, decode_worker, &jobs[t]) != 0) { decode_worker(&jobs[t]); tid[t] = 0; }
-    decode_worker(&jobs[0]);
+      if (pthread_create(&tid[t], NULL, fill_worker, &jobs[t]) != 0) { fill_worker(&jobs[t]); tid[t] = 0; }
+    fill_worker(&jobs[0]);
     int failed = jobs[0].failed;
     for (int t = 1; t < nthreads; t++)
     {
@@ -522,7 +634,7 @@ struct sequenceLibrary *ramx_load_sequence_subset_minimal(const char *twoBitName
     free(jobs); free(tid);
     if (failed) die255("%s is truncated", tb->path, 0, 0);
   }
-  LD_PHASE("decode");
+  LD_PHASE((mode & 1) ? "decode" : "read packed");
   uint64_t at = 0;
   for (int i = 0; i < n; i++)
   {
@@ -562,16 +674,122 @@ struct sequenceLibrary *ramx_load_sequence_subset_minimal(const char *twoBitName
 
   for (int i = 0; i < n; i++) { free(ranges[i].name); free(ranges[i].left_flag); free(ranges[i].right_flag); free(ranges[i].strand); }
   LD_PHASE("cores");
-  free(ranges); free(order); free(win); free(at_of);
-  while (nb_list) { struct nblocks *nx = nb_list->next_alloc; free(nb_list->start); free(nb_list->size); free(nb_list); nb_list = nx; }
+  free(ranges); free(order); free(win); free(rec_of);
+  for (int k = 0; k < nrec; k++) { free(rec[k].nb.start); free(rec[k].nb.size); }
+  free(rec);
+  if (pl)
+  {
+    int put = 0;
+    pthread_mutex_lock(&g_packed_mu);
+    for (int i = 0; i < RAMX_MAX_PACKED && !put; i++) if (g_packed[i].lib == NULL) { g_packed[i].lib = lib; g_packed[i].pl = pl; put = 1; }
+    __atomic_add_fetch(&g_packed_gen, 1, __ATOMIC_RELEASE);
+    pthread_mutex_unlock(&g_packed_mu);
+    if (!put) { fprintf(stderr, "RAMExtend(ramx): too many packed libraries alive (%d)\n", RAMX_MAX_PACKED); exit(1); }
+  }
+  else { free(at_of); free(byte_of); }
   tb_close(tb);
   return lib;
+}
+
+struct sequenceLibrary *ramx_load_sequence_subset_minimal(const char *twoBitName, const char *rangeBEDName,
+                                                          struct coreAlignment **core_align, int *num_cores,
+                                                          int max_flanking_bp)
+{
+  return load_subset(twoBitName, rangeBEDName, core_align, num_cores, max_flanking_bp, 1);
+}
+
+/* The same windows, never expanded to one byte per base on the host: lib->sequence is NULL, *packed holds
+ * the windows' bytes of the .2bit payload (kentsrc/twoBitNew.c:531-594: four bases per byte, first base in the most
+ * significant bits, T C A G = 0 1 2 3) and the runs of N (:597-613) in library coordinates. */
+struct sequenceLibrary *ramx_load_sequence_subset_packed(const char *twoBitName, const char *rangeBEDName,
+                                                         struct coreAlignment **core_align, int *num_cores,
+                                                         int max_flanking_bp, const ramx_packed_library **packed)
+{
+  struct sequenceLibrary *lib = load_subset(twoBitName, rangeBEDName, core_align, num_cores, max_flanking_bp, 2);
+  if (packed) *packed = ramx_packed_of(lib);
+  return lib;
+}
+
+/* bases [from, from + count) of a packed library as reference base codes (A C G T = 0..3, N = 99) */
+int ramx_packed_decode(const ramx_packed_library *pl, uint64_t from, uint64_t count, char *out)
+{
+  static const char val_to_code[4] = { 3, 1, 0, 2 };     /* T C A G (kentsrc/dnautil.h:23-27) -> sequence.h:7-15 */
+  if (!pl || (!out && count) || from > pl->length || count > pl->length - from) return RAMX_ERR_ARG;
+  if (count == 0) return RAMX_OK;
+  quad_init();
+  /* window of `from`: last win_start <= from */
+  int lo = 0, hi = pl->n_windows;
+  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (pl->win_start[mid] <= from) lo = mid; else hi = mid; }
+  int w = lo;
+  uint64_t p = from, done = 0;
+  while (done < count)
+  {
+    while (w + 1 < pl->n_windows && pl->win_start[w + 1] <= p) w++;
+    const uint64_t wend = pl->win_start[w + 1];
+    const unsigned char *b = pl->bytes + pl->win_byte[w];
+    uint64_t q = p - pl->win_start[w] + pl->win_phase[w];
+    const uint64_t stop = (from + count < wend) ? from + count : wend;
+    for (; p < stop && (q & 3); p++, q++, done++) out[done] = val_to_code[(b[q >> 2] >> (6 - 2 * (q & 3))) & 3];
+    for (; p + 4 <= stop; p += 4, q += 4, done += 4) memcpy(out + done, &g_quad[b[q >> 2]], 4);     /* four bases per lookup */
+    for (; p < stop; p++, q++, done++) out[done] = val_to_code[(b[q >> 2] >> (6 - 2 * (q & 3))) & 3];
+  }
+  /* runs of N that touch [from, from + count) */
+  if (pl->n_blocks > 0)
+  {
+    int a = 0, z = pl->n_blocks;                     /* first run that ends behind `from` */
+    while (a < z) { const int mid = (a + z) >> 1; if (pl->n_start[mid] + pl->n_len[mid] <= from) a = mid + 1; else z = mid; }
+    for (int k = a; k < pl->n_blocks && pl->n_start[k] < from + count; k++)
+    {
+      uint64_t s0 = pl->n_start[k], e0 = s0 + pl->n_len[k];
+      if (s0 < from) s0 = from;
+      if (e0 > from + count) e0 = from + count;
+      if (s0 < e0) memset(out + (s0 - from), RAMX_SYM_N, (size_t)(e0 - s0));
+    }
+  }
+  return RAMX_OK;
+}
+
+/* one base of a library of either kind (report and output writers) */
+int ramx_lib_code(const struct sequenceLibrary *lib, uint64_t at)
+{
+  if (lib->sequence) return lib->sequence[at];
+  static __thread const struct sequenceLibrary *c_lib = NULL;
+  static __thread const ramx_packed_library *c_pl = NULL;
+  static __thread unsigned c_gen = 0;
+  static __thread int c_w = 0;
+  const unsigned gen = __atomic_load_n(&g_packed_gen, __ATOMIC_ACQUIRE);
+  if (c_lib != lib || c_gen != gen) { c_pl = ramx_packed_of(lib); c_lib = lib; c_gen = gen; c_w = 0; }
+  const ramx_packed_library *pl = c_pl;
+  if (!pl || at >= pl->length) return RAMX_SYM_N;
+  int w = c_w;
+  if (w >= pl->n_windows || at < pl->win_start[w] || at >= pl->win_start[w + 1])
+  {
+    int lo = 0, hi = pl->n_windows;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (pl->win_start[mid] <= at) lo = mid; else hi = mid; }
+    c_w = w = lo;
+  }
+  static const char val_to_code[4] = { 3, 1, 0, 2 };
+  const uint64_t q = at - pl->win_start[w] + pl->win_phase[w];
+  int code = val_to_code[(pl->bytes[pl->win_byte[w] + (q >> 2)] >> (6 - 2 * (q & 3))) & 3];
+  if (pl->n_blocks > 0)
+  {
+    int a = -1, z = pl->n_blocks;                      /* last run that starts at or before `at` */
+    while (z - a > 1) { const int mid = (a + z) >> 1; if (pl->n_start[mid] <= at) a = mid; else z = mid; }
+    if (a >= 0 && at < pl->n_start[a] + pl->n_len[a]) code = RAMX_SYM_N;
+  }
+  return code;
 }
 
 void ramx_free_library(struct sequenceLibrary *lib, struct coreAlignment *cores)
 {
   if (lib)
   {
+    ramx_packed_library *pl = NULL;
+    pthread_mutex_lock(&g_packed_mu);
+    for (int i = 0; i < RAMX_MAX_PACKED; i++) if (g_packed[i].lib == lib) { pl = g_packed[i].pl; g_packed[i].lib = NULL; g_packed[i].pl = NULL; }
+    __atomic_add_fetch(&g_packed_gen, 1, __ATOMIC_RELEASE);
+    pthread_mutex_unlock(&g_packed_mu);
+    packed_free(pl);
     for (int i = 0; i < lib->count; i++) free(lib->identifiers[i]);
     free(lib->identifiers); free(lib->boundaries); free(lib->offsets); free(lib->sequence);
     free(lib);

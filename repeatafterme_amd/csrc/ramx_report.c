@@ -29,7 +29,7 @@ static int code_compl(int c)                   /* sequence.c:1141-1160 */
 static void append_base(char *dst, const struct sequenceLibrary *lib, uint64_t at, int complement)
 {
   size_t n = strlen(dst);
-  int code = lib->sequence[at];
+  int code = ramx_lib_code(lib, at);      /* one byte per base, or the packed twin */
   dst[n] = code_to_char(complement ? code_compl(code) : code);
   dst[n + 1] = 0;
 }
@@ -51,51 +51,23 @@ static int is_blank(const struct coreAlignment *c)
   return c->seqIdx == 0 && c->leftSeqPos == 0 && c->rightSeqPos == 0;
 }
 
-void ramx_print_core_edges(struct coreAlignment *coreAlign, struct sequenceLibrary *seqLib, char omitBlanks, char debug)
+struct edges_ctx
 {
-  struct coreAlignment *c;
-  uint64_t maxPos = 0;
-  int maxIDLen = 0, maxIdx = 1, n = 0;
-  char num[64];
+  const struct coreAlignment **arr;
+  const struct sequenceLibrary *seqLib;
+  int maxIDLen, maxPosLen, maxSArrayLen, maxIdxLen, debug;
+};
 
-  for (c = coreAlign; c != NULL; c = c->next)
+/* rows [lo_i, hi_i) of the core table (report.c:161-502) */
+static void edges_rows(int lo_i, int hi_i, FILE **outs, void *user)
+{
+  const struct edges_ctx *t = (const struct edges_ctx *)user;
+  const struct sequenceLibrary *seqLib = t->seqLib;
+  const int maxIDLen = t->maxIDLen, maxPosLen = t->maxPosLen, maxSArrayLen = t->maxSArrayLen, maxIdxLen = t->maxIdxLen, debug = t->debug;
+  FILE *out = outs[0];
+  for (int n = lo_i; n < hi_i; n++)
   {
-    if (omitBlanks == 1 && is_blank(c)) break;
-    uint64_t off = (seqLib->offsets != NULL && seqLib->offsets[c->seqIdx] > 0) ? seqLib->offsets[c->seqIdx] : 0;
-    uint64_t lo = c->seqIdx > 0 ? seqLib->boundaries[c->seqIdx - 1] : 0;
-    int idl = (int)strlen(seqLib->identifiers[c->seqIdx]);
-    if (idl > maxIDLen) maxIDLen = idl;
-    if (off + c->leftSeqPos - lo + 1 > maxPos) maxPos = off + c->leftSeqPos - lo + 1;
-    if (off + c->rightSeqPos - lo + 1 > maxPos) maxPos = off + c->rightSeqPos - lo + 1;
-    maxIdx++;
-  }
-  if (maxIDLen > 50) maxIDLen = 50;
-  if (maxIDLen < 5) maxIDLen = 5;
-  snprintf(num, sizeof(num), "%ld", (long)maxPos);
-  int maxPosLen = (int)strlen(num);
-  snprintf(num, sizeof(num), "%ld", (long)seqLib->length);
-  if (maxPosLen * 2 + 1 < 9) maxPosLen = 9;
-  const int maxSArrayLen = (int)strlen(num);
-  int maxIdxLen = (int)floor(log10(maxIdx)) + 1;
-  if (maxIdxLen < 4) maxIdxLen = 4;
-
-  if (debug == 1)
-  {
-    printf("%-*s %-*s %-*s %-*s %-*s  Left-Flank           Core           Right-Flank  %-*s Hard-Bounds Soft-Bounds BoundFlags(Lower/Upper)\n",
-           maxIdxLen, "Seq", maxIDLen, "Ident", maxPosLen * 2 + 1, "BED-range", 6, "Orient", 4, "L/R?",
-           maxSArrayLen, "seq[]-core");
-    printf("------------------------------------------------------------------------------------------------------------------------------------------------------------\n");
-  }
-  else
-  {
-    printf("%-*s %-*s %-*s %-*s %-*s  Left-Flank           Core           Right-Flank\n",
-           maxIdxLen, "Seq", maxIDLen, "Ident", maxPosLen * 2 + 1, "BED-range", 6, "Orient", 4, "L/R?");
-    printf("------------------------------------------------------------------------------------\n");
-  }
-
-  for (c = coreAlign; c != NULL; c = c->next)
-  {
-    if (omitBlanks == 1 && is_blank(c)) break;
+    const struct coreAlignment *c = t->arr[n];
     const char *ident = seqLib->identifiers[c->seqIdx];
     uint64_t off = (seqLib->offsets != NULL && seqLib->offsets[c->seqIdx] > 0) ? seqLib->offsets[c->seqIdx] : 0;
     uint64_t lo = c->seqIdx > 0 ? seqLib->boundaries[c->seqIdx - 1] : 0;
@@ -149,7 +121,7 @@ void ramx_print_core_edges(struct coreAlignment *coreAlign, struct sequenceLibra
       else if (c->rightSeqPos - disp < lo) disp = (int)(c->rightSeqPos - lo);
       for (j = 0; j > -disp; j--) append_base(rightExt, seqLib, c->rightSeqPos + j - 1, 1);
       if (disp < 10) strcat(rightExt, "*");
-      printf("%-*d %s %s -      %d/%d ", maxIdxLen, n, idBuff, rangeCol, c->leftExtendable, c->rightExtendable);
+      fprintf(out, "%-*d %s %s -      %d/%d ", maxIdxLen, n, idBuff, rangeCol, c->leftExtendable, c->rightExtendable);
     }
     else
     {
@@ -173,17 +145,74 @@ void ramx_print_core_edges(struct coreAlignment *coreAlign, struct sequenceLibra
       if (c->rightSeqPos + disp > hi) disp = (int)(hi - c->rightSeqPos);
       for (j = 1; j <= disp; j++) append_base(rightExt, seqLib, c->rightSeqPos + j, 0);
       if (disp < 10) strcat(rightExt, "*");
-      printf("%-*d %s %s +      %d/%d ", maxIdxLen, n, idBuff, rangeCol, c->leftExtendable, c->rightExtendable);
+      fprintf(out, "%-*d %s %s +      %d/%d ", maxIdxLen, n, idBuff, rangeCol, c->leftExtendable, c->rightExtendable);
     }
-    if (c->leftExtendable) printf("%11s", leftExt);
-    else printf("           ");
-    printf(" [%-24s] ", coreSeq);
-    if (c->rightExtendable) printf("%-11s", rightExt);
-    else printf("           ");
+    if (c->leftExtendable) fprintf(out, "%11s", leftExt);
+    else fprintf(out, "           ");
+    fprintf(out, " [%-24s] ", coreSeq);
+    if (c->rightExtendable) fprintf(out, "%-11s", rightExt);
+    else fprintf(out, "           ");
     if (debug == 1)
-      printf(" %s %ld-%ld %ld-%ld %s/%s", sarrCol, (long)lo, (long)hi, (long)c->lowerSeqBound, (long)c->upperSeqBound,
+      fprintf(out, " %s %ld-%ld %ld-%ld %s/%s", sarrCol, (long)lo, (long)hi, (long)c->lowerSeqBound, (long)c->upperSeqBound,
              flag_name(c->lowerSeqBoundFlag), flag_name(c->upperSeqBoundFlag));
-    printf("\n");
-    n++;
+    fprintf(out, "\n");
+  }
+}
+
+void ramx_print_core_edges(struct coreAlignment *coreAlign, struct sequenceLibrary *seqLib, char omitBlanks, char debug)
+{
+  struct coreAlignment *c;
+  uint64_t maxPos = 0;
+  int maxIDLen = 0, maxIdx = 1;
+  char num[64];
+
+  for (c = coreAlign; c != NULL; c = c->next)
+  {
+    if (omitBlanks == 1 && is_blank(c)) break;
+    uint64_t off = (seqLib->offsets != NULL && seqLib->offsets[c->seqIdx] > 0) ? seqLib->offsets[c->seqIdx] : 0;
+    uint64_t lo = c->seqIdx > 0 ? seqLib->boundaries[c->seqIdx - 1] : 0;
+    int idl = (int)strlen(seqLib->identifiers[c->seqIdx]);
+    if (idl > maxIDLen) maxIDLen = idl;
+    if (off + c->leftSeqPos - lo + 1 > maxPos) maxPos = off + c->leftSeqPos - lo + 1;
+    if (off + c->rightSeqPos - lo + 1 > maxPos) maxPos = off + c->rightSeqPos - lo + 1;
+    maxIdx++;
+  }
+  if (maxIDLen > 50) maxIDLen = 50;
+  if (maxIDLen < 5) maxIDLen = 5;
+  snprintf(num, sizeof(num), "%ld", (long)maxPos);
+  int maxPosLen = (int)strlen(num);
+  snprintf(num, sizeof(num), "%ld", (long)seqLib->length);
+  if (maxPosLen * 2 + 1 < 9) maxPosLen = 9;
+  const int maxSArrayLen = (int)strlen(num);
+  int maxIdxLen = (int)floor(log10(maxIdx)) + 1;
+  if (maxIdxLen < 4) maxIdxLen = 4;
+
+  if (debug == 1)
+  {
+    printf("%-*s %-*s %-*s %-*s %-*s  Left-Flank           Core           Right-Flank  %-*s Hard-Bounds Soft-Bounds BoundFlags(Lower/Upper)\n",
+           maxIdxLen, "Seq", maxIDLen, "Ident", maxPosLen * 2 + 1, "BED-range", 6, "Orient", 4, "L/R?",
+           maxSArrayLen, "seq[]-core");
+    printf("------------------------------------------------------------------------------------------------------------------------------------------------------------\n");
+  }
+  else
+  {
+    printf("%-*s %-*s %-*s %-*s %-*s  Left-Flank           Core           Right-Flank\n",
+           maxIdxLen, "Seq", maxIDLen, "Ident", maxPosLen * 2 + 1, "BED-range", 6, "Orient", 4, "L/R?");
+    printf("------------------------------------------------------------------------------------\n");
+  }
+
+  /* the rows: formatted chunk by chunk on the host's cores, written in order */
+  {
+    int cnt = 0;
+    for (c = coreAlign; c != NULL; c = c->next) { if (omitBlanks == 1 && is_blank(c)) break; cnt++; }
+    const struct coreAlignment **arr = (const struct coreAlignment **)malloc(sizeof(*arr) * (size_t)(cnt ? cnt : 1));
+    cnt = 0;
+    for (c = coreAlign; c != NULL; c = c->next) { if (omitBlanks == 1 && is_blank(c)) break; arr[cnt++] = c; }
+    struct edges_ctx ctx;
+    ctx.arr = arr; ctx.seqLib = seqLib; ctx.maxIDLen = maxIDLen; ctx.maxPosLen = maxPosLen; ctx.maxSArrayLen = maxSArrayLen;
+    ctx.maxIdxLen = maxIdxLen; ctx.debug = debug;
+    FILE *outs[1] = { stdout };
+    ramx_parallel_chunks(cnt, 1, outs, edges_rows, &ctx);
+    free(arr);
   }
 }

@@ -68,6 +68,65 @@ def load_sequence_subset_minimal(twobit: str, ranges: str, max_flanking_bp: int)
     return fs
 
 
+class _Packed(C.Structure):  # include/ramx.h ramx_packed_library
+    _fields_ = [("length", C.c_uint64), ("n_windows", C.c_int32), ("win_start", C.POINTER(C.c_uint64)),
+                ("win_byte", C.POINTER(C.c_uint64)), ("win_phase", C.POINTER(C.c_uint8)), ("bytes", C.POINTER(C.c_uint8)),
+                ("n_bytes", C.c_uint64), ("n_start", C.POINTER(C.c_uint64)), ("n_len", C.POINTER(C.c_uint32)),
+                ("n_blocks", C.c_int32)]
+
+
+def load_sequence_subset_packed(twobit: str, ranges: str, max_flanking_bp: int):
+    """ramx_load_sequence_subset_packed: the same windows kept as the .2bit file stores them.  Returns
+    (FlankSet whose sequence was decoded through ramx_packed_decode, dict with the packed tables) -- test mirror."""
+    L = _lib.lib()
+    L.ramx_load_sequence_subset_packed.restype = C.POINTER(_SeqLib)
+    L.ramx_load_sequence_subset_packed.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.POINTER(_Core)), C.POINTER(C.c_int),
+                                                   C.c_int, C.POINTER(C.POINTER(_Packed))]
+    L.ramx_packed_decode.argtypes = [C.POINTER(_Packed), C.c_uint64, C.c_uint64, C.c_void_p]
+    L.ramx_free_library.argtypes = [C.POINTER(_SeqLib), C.POINTER(_Core)]
+    head = C.POINTER(_Core)()
+    n = C.c_int()
+    pk = C.POINTER(_Packed)()
+    lp = L.ramx_load_sequence_subset_packed(twobit.encode(), ranges.encode(), C.byref(head), C.byref(n), max_flanking_bp, C.byref(pk))
+    sl = lp.contents
+    assert not sl.sequence, "a packed library has no one-byte-per-base sequence"
+    p = pk.contents
+    nw, nb = p.n_windows, p.n_blocks
+    tables = dict(length=int(p.length), n_windows=nw, n_bytes=int(p.n_bytes), n_blocks=nb,
+                  win_start=np.array([p.win_start[i] for i in range(nw + 1)], np.uint64),
+                  win_byte=np.array([p.win_byte[i] for i in range(nw + 1)], np.uint64),
+                  win_phase=np.array([p.win_phase[i] for i in range(nw)], np.uint8),
+                  n_start=np.array([p.n_start[i] for i in range(nb)], np.uint64),
+                  n_len=np.array([p.n_len[i] for i in range(nb)], np.uint32))
+    seq = np.zeros(int(sl.length), np.int8)
+    if sl.length:
+        _lib.check(L.ramx_packed_decode(pk, 0, sl.length, seq.ctypes.data), "ramx_packed_decode")
+
+    def decode(frm: int, count: int) -> np.ndarray:
+        out = np.zeros(count, np.int8)
+        _lib.check(L.ramx_packed_decode(pk, frm, count, out.ctypes.data), "ramx_packed_decode")
+        return out
+    tables["pieces"] = [(f, c, decode(f, c)) for f, c in _sample_ranges(int(sl.length))]
+    bounds = np.array([sl.boundaries[i] for i in range(sl.count + 1)], np.uint64)
+    offs = np.array([sl.offsets[i] for i in range(sl.count + 1)], np.uint64)
+    ids = [sl.identifiers[i].decode() for i in range(sl.count)]
+    fs = FlankSet(sequence=seq, boundaries=bounds, cores=cores_from_list(head, n.value), offsets=offs, identifiers=ids)
+    L.ramx_free_library(lp, head)
+    return fs, tables
+
+
+def _sample_ranges(length: int):
+    """(from, count) pieces for spot checks of ramx_packed_decode: single bases, window-straddling stretches, the ends."""
+    rng = np.random.default_rng(length)
+    out = [(0, min(length, 1)), (max(length - 1, 0), min(length, 1))]
+    for _ in range(40):
+        if length == 0:
+            break
+        f = int(rng.integers(0, length))
+        out.append((f, int(min(length - f, rng.integers(1, 700)))))
+    return out
+
+
 # ----------------------------------------------------------------------------- writers (formats: SURVEY.md App. A)
 
 _CODE_TO_2BIT = np.array([2, 1, 3, 0], np.uint8)   # A,C,G,T -> 2bit T=0 C=1 A=2 G=3

@@ -13,7 +13,7 @@ import pytest
 from oracle import pyoracle as po
 from repeatafterme_amd import _lib
 from repeatafterme_amd.loader import (_Core, _SeqLib, cores_from_list, flankset_from_c, load_sequence_subset_minimal,
-                                      write_ranges, write_twobit)
+                                      load_sequence_subset_packed, write_ranges, write_twobit)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = os.path.join(ROOT, "tests", "golden")
@@ -200,3 +200,60 @@ def test_overlap_avoidance_vs_quadratic_restatement():
             os.dup2(saved, 1); os.close(devnull); os.close(saved)
         assert [int(c.lowerSeqBound) for c in arr] == lowers and [int(c.upperSeqBound) for c in arr] == uppers, trial
         assert [[c.lowerSeqBoundFlag, c.upperSeqBoundFlag] for c in arr] == flags
+
+
+# ---- the windows kept packed (4 bases per byte, as in the .2bit file), never one byte per base ----------
+
+@pytest.mark.parametrize("stem,maxflank", [("extension-test2", 10014), ("genome_0", 60), ("genome_1", 314), ("genome_2", 2000),
+                                           ("genome_3", 5), ("genome_ov", 150)])
+@pytest.mark.parametrize("threads", ["1", "5"])
+def test_packed_loader_equals_byte_loader(stem, maxflank, threads, monkeypatch):
+    """ramx_load_sequence_subset_packed against ramx_load_sequence_subset_minimal on the golden inputs (cores on both strands,
+    several per record, N runs, windows that start at every phase of a packed byte): same cores / boundaries / offsets /
+    identifiers, ramx_packed_decode gives back exactly the one-byte-per-base library, whole and in pieces; the packed
+    payload is a quarter of it."""
+    monkeypatch.setenv("RAMX_LOADER_THREADS", threads)
+    tb, tsv = os.path.join(G, "inputs", stem + ".2bit"), os.path.join(G, "inputs", stem + ".tsv")
+    a = load_sequence_subset_minimal(tb, tsv, maxflank)
+    b, t = load_sequence_subset_packed(tb, tsv, maxflank)
+    assert np.array_equal(a.sequence, b.sequence)
+    assert np.array_equal(a.boundaries, b.boundaries) and np.array_equal(a.offsets, b.offsets) and a.identifiers == b.identifiers
+    for f in ("left_pos", "right_pos", "lower", "upper", "orient", "left_ext", "right_ext", "seq_idx", "lower_flag", "upper_flag"):
+        assert np.array_equal(getattr(a.cores, f), getattr(b.cores, f)), f
+    assert t["length"] == len(a.sequence) and t["n_windows"] == a.cores.n
+    assert np.array_equal(t["win_start"][1:], a.boundaries[:a.cores.n])
+    assert t["n_bytes"] <= len(a.sequence) // 4 + 2 * a.cores.n
+    for frm, cnt, piece in t["pieces"]:
+        assert np.array_equal(piece, a.sequence[frm:frm + cnt]), (frm, cnt)
+    # every N of the library lies in exactly one run of the table, and nothing else does
+    isn = np.zeros(len(a.sequence), bool)
+    for s0, ln in zip(t["n_start"], t["n_len"]):
+        assert not isn[int(s0):int(s0) + int(ln)].any()
+        isn[int(s0):int(s0) + int(ln)] = True
+    assert np.array_equal(isn, a.sequence == 99)
+
+
+def test_packed_loader_synthetic_phases_and_n_runs(tmp_path):
+    """Windows starting at every phase 0..3 of a packed byte, N runs that straddle window edges and byte edges, a record
+    whose last byte is partial: packed == byte loader."""
+    rng = np.random.default_rng(4)
+    recs, rows = [], []
+    for r in range(6):
+        n = 997 + r
+        codes = rng.integers(0, 4, size=n).astype(np.int8)
+        for _ in range(5):
+            s0 = int(rng.integers(0, n - 40)); codes[s0:s0 + int(rng.integers(1, 37))] = 99
+        recs.append((f"rec{r}", codes))
+        pos = 50 + r
+        for k in range(4):
+            rows.append((f"rec{r}", pos, pos + 9 + k, int(rng.integers(0, 2)), 1, "+-"[(r + k) & 1]))
+            pos += 150 + k
+    tb, tsv = str(tmp_path / "p.2bit"), str(tmp_path / "p.tsv")
+    write_twobit(tb, recs); write_ranges(tsv, rows)
+    for maxflank in (7, 61, 5000):
+        a = load_sequence_subset_minimal(tb, tsv, maxflank)
+        b, t = load_sequence_subset_packed(tb, tsv, maxflank)
+        assert np.array_equal(a.sequence, b.sequence) and set(t["win_phase"].tolist()) == {0, 1, 2, 3}
+        assert (a.sequence == 99).any()
+        for frm, cnt, piece in t["pieces"]:
+            assert np.array_equal(piece, a.sequence[frm:frm + cnt])
