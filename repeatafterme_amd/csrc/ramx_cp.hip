@@ -132,7 +132,7 @@ int ramx_cp_device_plan(int W, int n, int cus, int wide, int *K, int *threads, i
     // row lives in registers, seven when it lives in LDS -- and for those, before giving up lanes per flank, the plain
     // order without a vote wave (eight band waves again).
     const bool syncw = cells <= RAMX_CP_SYNCW_MAXC, regs = cells <= RAMX_CP_SYNCW_REGC;
-    int cand_t[4], cand_vw[4], nc = 0;
+    int cand_t[5], cand_vw[5], nc = 0;
     if (ftv)
     {
       const int vw = syncw && (regs || !no_vw);
@@ -145,6 +145,9 @@ int ramx_cp_device_plan(int W, int n, int cus, int wide, int *K, int *threads, i
       // the larger number of workgroups costs (profiles/r03_ab_threads.log: N = 1,000: 1.43 us per column against 1.58 with
       // four band waves, N = 3,000: 1.50 against 1.62)
       if (!wide) { cand_t[nc] = 256; cand_vw[nc++] = 1; cand_t[nc] = 320; cand_vw[nc++] = 1; }
+      // seven band waves + the vote wave before eight + one: the vote wave then shares its SIMD with one band wave instead of
+      // two (profiles/r03_ab_k.log: 12,500 flanks, 8 lanes per flank: 2.23 against 2.33 us per column)
+      cand_t[nc] = tmax; cand_vw[nc++] = 1;
       cand_t[nc] = tmax + 64; cand_vw[nc++] = 1;
     }
     else if (syncw)

@@ -179,7 +179,8 @@ def test_cp_scoring_bounds_fall_back(monkeypatch):
 
 @pytest.mark.parametrize("W,n,K,matrix", [(40, 1000, 16, "14p43g"), (40, 5000, 16, "14p43g"), (14, 3000, 16, "20p43g"),
                                           (80, 2500, 16, "20p43g"), (20, 20000, 4, "repeatscout"), (40, 700, 16, "25p43g"),
-                                          (40, 12000, 8, "18p43g"),     # eight band waves + vote wave, saved row in registers
+                                          (40, 12000, 8, "18p43g"),     # seven band waves + vote wave, saved row in registers
+                                          (40, 15000, 8, "14p43g"),     # eight band waves + vote wave (576 threads)
                                           (40, 20000, 4, "14p43g"),     # 21 cells per lane: seven band waves + vote wave, saved row in LDS
                                           (40, 30000, 4, "18p43g"),     # 21 cells per lane at the capacity edge: vote, then band (no vote wave)
                                           (80, 10000, 8, "20p43g")])    # W = 80, 21 cells per lane, vote wave
