@@ -175,7 +175,7 @@ static int64_t clamp64(int64_t v, int64_t lo, int64_t hi) { return v < lo ? lo :
  * Resolve one core into a flank for `direction` (reference bnw_extend.c:778-788, 824-868).
  * With p(t) = start + step * t, t = offset + row, the reference's unsigned index logic is
  * equivalent to "out of bounds iff p < lowerSeqBound || p > upperSeqBound || p < 0"
- * (SURVEY.md App. D rule 1; tests/test_flank_rule.py re-checks it against the oracle).
+ * (SURVEY.md App. D rule 1; tests/test_scoring_and_flanks.py re-checks it against the oracle).
  */
 static void resolve_flank(int direction, int64_t left_pos, int64_t right_pos, int64_t lower, int64_t upper,
                           int orient, int W, int L, ramx_flank *f)

@@ -356,10 +356,13 @@ __device__ __forceinline__ void cp_reduce(const CpLane &ln, const CpTabs &tabs, 
 // ------------------------------------------------------------------------------------------
 // the kernel: K lanes per flank.
 //   DEV = false   one workgroup = one family (batch mode, seam 1 for families up to one workgroup): block-local vote
-//   DEV = true    one flank set spread over the grid (cooperative launch, one workgroup per CU): the per-column vote
-//                 goes through the sharded ticket words of the persistent kernel (ramx_kernels_resident.h: every
-//                 workgroup adds its four partial sums, tagged with an arrival ticket, into one of 32 shards; wave 0 of
-//                 every workgroup polls the shards of the column it is about to start).  Single GPU only.
+//   DEV = true    one flank set spread over the grid (plain launch of at most one workgroup per CU; several sets per launch
+//                 in batch mode): the per-column vote goes through the sharded ticket words of the persistent kernel
+//                 (ramx_kernels_resident.h: every workgroup adds its four partial sums, tagged with an arrival ticket, into
+//                 one of 32 shards; wave 0 of every workgroup polls the shards of the column it is about to start); with
+//                 the flanks sharded over ranks the ranks' totals cross the devices through the mailboxes (cross_device).
+//                 Co-residency is not guaranteed by the launch: every spin is bounded, a timeout raises the set's error
+//                 word, every workgroup of the set leaves and the host repeats the work on another route.
 // ------------------------------------------------------------------------------------------
 #ifndef CP_SYNC_FIRST_SLEEP
 #define CP_SYNC_FIRST_SLEEP 4   // s_sleep units (64 clocks) before the vote wave's first look at the tickets of a row

@@ -10,7 +10,7 @@
 //
 // For W known at compile time and N <= (resident waves) x 64 the row of a flank (2 x (2W+1) int32) fits the
 // lane's registers, so the row never travels: HBM sees only the base words (~12 words per flank per column) and
-// the 32-byte vote.  All L columns run inside one cooperative launch; the dependent-launch boundary of the
+// the 32-byte vote.  All L columns run inside ONE launch; the dependent-launch boundary of the
 // streaming kernel becomes a device-wide barrier that is fused with the vote:
 //
 //   column c, every block:   4 x int64 atomicAdd into shard (blockIdx % 32) of vote set (c+1) % 4.  Each add
@@ -27,8 +27,12 @@
 //   it has to be and nobody stalls for it (with three sets block 0 had to wait for its stores before every add).
 //
 // Placement independent: only agent-scope atomics / atomic loads touch shared words, no assumption on which
-// XCD a block runs; co-residency is checked by hipLaunchCooperativeKernel and every spin is bounded (a timeout
-// raises `err` and every block leaves).  Multi-GPU runs keep the per-column launches (RCCL sits between them).
+// XCD a block runs.  The launch is a PLAIN one (a cooperative launch made profiled processes crash at exit, DESIGN.md
+// section 7): the host launches at most one workgroup per CU and never more workgroups than CUs, which makes the grid
+// co-resident on an idle device but is no guarantee next to a co-tenant -- correctness therefore rests on the BOUNDED
+// spins (a timeout raises `err`, every block leaves) and on the host repeating the direction with the per-column
+// launches when that happens (ramx_dev_run_direction; batch mode: ramx_dev_run_families repeats the affected
+// families).  Multi-GPU runs exchange the vote through the mailboxes below, or fall back to RCCL between per-column launches.
 
 #ifndef PRK_SHARD_BYTES
 #define PRK_SHARD_BYTES 256   // 64 (one line per shard) measured 1.5-2 % slower: neighbouring shards share a memory channel

@@ -10,7 +10,7 @@ for spec in sys.argv[2:]:
     name, flanks, cols = spec.split(":")
     doc = json.load(open(os.path.join(root, "profiles", f"{tag}_pmc_{name}.json")))
     for kernel, ent in doc.items():
-        m = re.search(r"ramx_cp_kernelILi(\d+)ELi(\d+)ELb1", kernel)
+        m = re.search(r"ramx_cp_kernelILi(\d+)ELi(\d+)ELb1", kernel) or re.search(r"ramx_cp_kernel<(\d+), (\d+), true", kernel)
         if not m:
             continue
         a = ent["avg_per_dispatch"]
