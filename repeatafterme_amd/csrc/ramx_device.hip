@@ -121,7 +121,9 @@ struct ramx_dev
   hipStream_t cls_stream[RAMX_NGROUP]; hipEvent_t cls_ready, cls_done[RAMX_NGROUP]; int cls_init;   // batch mode: one stream per workgroup shape
   int force_chain;   // RAMX_FORCE_CHAIN=1: always run the full candidate recurrence (test hook)
   ramx_row_trace_cb trace_cb; void *trace_user;   // -outmat: per-row trace (forces the per-column launches)
+  ramx_row_verbose_cb verbose_cb; void *verbose_user;   // -vvvv: per-row candidate trace (per-column launches, full candidate recurrence)
   signed char *d_dbg_codes; int2 *d_dbg_best; size_t cap_dbg_codes, cap_dbg_best;
+  int *d_dbg_cand; int2 *d_dbg_gap; size_t cap_dbg_cand, cap_dbg_gap;
   CpDevDesc *d_devdesc; size_t cap_devdesc;       // device-wide cell-parallel launches: one descriptor per workgroup
   PShard *d_vote_sets; size_t cap_vote_sets; unsigned *d_err_sets; size_t cap_err_sets;   // batch mode: per-set vote / error words
   int cp_flanks_ok;    // begin_direction: every flank is empty or has t_lo <= 0 (what the cell-parallel kernels take)
@@ -198,7 +200,7 @@ extern "C" void ramx_dev_destroy(ramx_dev *d)
     (void)hipEventDestroy(d->cls_ready);
   }
   if (d->devbox) (void)hipFree(d->devbox);
-  (void)hipFree(d->d_fam); (void)hipFree(d->d_famctl); (void)hipFree(d->d_cpstate); (void)hipFree(d->d_dbg_codes); (void)hipFree(d->d_dbg_best); (void)hipFree(d->d_devdesc); (void)hipFree(d->d_vote_sets); (void)hipFree(d->d_err_sets);
+  (void)hipFree(d->d_fam); (void)hipFree(d->d_famctl); (void)hipFree(d->d_cpstate); (void)hipFree(d->d_dbg_codes); (void)hipFree(d->d_dbg_best); (void)hipFree(d->d_dbg_cand); (void)hipFree(d->d_dbg_gap); (void)hipFree(d->d_devdesc); (void)hipFree(d->d_vote_sets); (void)hipFree(d->d_err_sets);
   if (d->hostbox_mirror) (void)hipFree(d->hostbox_mirror);
   if (d->d_peer) (void)hipFree(d->d_peer);
   for (int i = 0; i < 2; i++) if (d->ev_chk[i]) (void)hipEventDestroy(d->ev_chk[i]);
@@ -364,11 +366,14 @@ static void launch_column(ramx_dev *d, const KArgs &a)
     hipLaunchKernelGGL((ramx_column_kernel<INIT, true, 256>), grid, block, 0, d->stream, a);
 }
 
-// -outmat trace: the DBG instantiation also writes the per-cell path codes and the row's best cell of every flank
-static void launch_column_trace(ramx_dev *d, const KArgs &a)
+// -outmat trace: the DBG instantiation also writes the per-cell path codes and the row's best cell of every flank;
+// -vvvv (a.dbg_cand != NULL): the full candidate recurrence, whose rows' best cells and end-cell gap states are written too
+static void launch_column_trace(ramx_dev *d, const KArgs &a, bool init = false)
 {
   const int tiles = d->Np / 64;
   const dim3 grid((tiles + 3) / 4), block(256);
+  if (init) { hipLaunchKernelGGL((ramx_column_kernel<true, true, 256, true>), grid, block, 0, d->stream, a); return; }
+  if (a.dbg_cand != NULL) { hipLaunchKernelGGL((ramx_column_kernel<false, true, 256, true>), grid, block, 0, d->stream, a); return; }
   if (a.go <= 0 && a.ge <= 0 && !d->force_chain)
     hipLaunchKernelGGL((ramx_column_kernel<false, false, 256, true>), grid, block, 0, d->stream, a);
   else
@@ -1226,7 +1231,54 @@ extern "C" int ramx_dev_run_direction(ramx_dev *d, ramx_run_info *info)
   bool persistent = false;
   // ---- cell-parallel route (single GPU): K lanes per flank, the whole direction in one cooperative launch of at most one
   // workgroup per CU; boundary row and every column inside the kernel ---------------------------------------------------
-  const bool tracing = d->trace_cb != NULL;
+  const bool tracing = d->trace_cb != NULL || d->verbose_cb != NULL;
+  const bool verbose_trace = d->verbose_cb != NULL;
+  const int Bt = 2 * p.bandwidth + 1;
+  // hands the DBG buffers of the launch that has just completed to the callbacks
+  auto deliver_trace = [&](int r, int besta) -> int
+  {
+    std::vector<int8_t> codes;
+    std::vector<int2> best((size_t)d->Nx + 1), gaps((size_t)d->Nx + 1);
+    std::vector<int32_t> bs((size_t)d->Nx + 1), bi((size_t)d->Nx + 1), gfl(2 * (size_t)d->Nx + 2), cand(16 * (size_t)d->Nx + 16);
+    if (d->Nx && r >= 0) HIPCHK(hipMemcpy(best.data(), d->d_dbg_best, (size_t)d->Nx * sizeof(int2), hipMemcpyDeviceToHost));
+    for (int i = 0; i < d->Nx; i++) { bs[i] = best[i].x; bi[i] = best[i].y; }
+    if (d->trace_cb && r >= 0)
+    {
+      codes.resize((size_t)d->Nx * Bt + 1);
+      if (d->Nx) HIPCHK(hipMemcpy(codes.data(), d->d_dbg_codes, (size_t)d->Nx * Bt, hipMemcpyDeviceToHost));
+      d->trace_cb(r, besta, codes.data(), bs.data(), bi.data(), d->trace_user);
+    }
+    if (d->verbose_cb)
+    {
+      if (d->Nx)
+      {
+        HIPCHK(hipMemcpy(cand.data(), d->d_dbg_cand, (size_t)d->Nx * 16 * sizeof(int), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(gaps.data(), d->d_dbg_gap, (size_t)d->Nx * sizeof(int2), hipMemcpyDeviceToHost));
+      }
+      for (int i = 0; i < d->Nx; i++) { gfl[2 * i] = gaps[i].x; gfl[2 * i + 1] = gaps[i].y; }
+      d->verbose_cb(r, besta, d->Nx, bs.data(), bi.data(), gfl.data(), cand.data(), d->verbose_user);
+    }
+    return RAMX_OK;
+  };
+  auto trace_buffers = [&](KArgs &ka) -> int
+  {
+    int trc;
+    if ((trc = ensure(&d->d_dbg_best, &d->cap_dbg_best, (size_t)d->Np * sizeof(int2))) != RAMX_OK) return trc;
+    ka.dbg_best = d->d_dbg_best;
+    ka.dbg_codes = NULL; ka.dbg_cand = NULL; ka.dbg_gap = NULL;
+    if (d->trace_cb)
+    {
+      if ((trc = ensure(&d->d_dbg_codes, &d->cap_dbg_codes, (size_t)d->Np * Bt)) != RAMX_OK) return trc;
+      ka.dbg_codes = d->d_dbg_codes;
+    }
+    if (verbose_trace)
+    {
+      if ((trc = ensure(&d->d_dbg_cand, &d->cap_dbg_cand, (size_t)d->Np * 16 * sizeof(int))) != RAMX_OK) return trc;
+      if ((trc = ensure(&d->d_dbg_gap, &d->cap_dbg_gap, (size_t)d->Np * sizeof(int2))) != RAMX_OK) return trc;
+      ka.dbg_cand = d->d_dbg_cand; ka.dbg_gap = d->d_dbg_gap;
+    }
+    return RAMX_OK;
+  };
   // Multi-rank: the vote crosses the devices through the mailboxes (ramx_dev_peer_* set-up), exactly as in the
   // lane-per-flank persistent kernel; every rank must take this route or none (one agreement before, one after).
   const bool cp_multi_ok = !multi || (d->peer_ready && d->nranks >= 2 && L < 65536 && getenv("RAMX_NO_PEER") == NULL);
@@ -1365,7 +1417,16 @@ extern "C" int ramx_dev_run_direction(ramx_dev *d, ramx_run_info *info)
   // K(-1): boundary row + candidates of row 0
   a.r = -1; a.S_in = d->d_state[0]; a.S_out = d->d_state[1]; a.ctl_in = d->d_ctl; a.ctl_out = d->d_ctl + 1;
   a.sums_in = slot(0); a.sums_out = slot(0); a.sums_zero = slot(1); a.nshards_in = NSHARD;
-  launch_column<true>(d, a);
+  if (verbose_trace)
+  {
+    int trc = trace_buffers(a);
+    if (trc != RAMX_OK) return trc;
+    launch_column_trace(d, a, true);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(d->stream));
+    if ((trc = deliver_trace(-1, 0)) != RAMX_OK) return trc;
+  }
+  else launch_column<true>(d, a);
   HIPCHK(hipGetLastError());
   {
     // the in-place row buffer holds S(-1) after K(-1); d_ctl[1] holds the initial control block, the persistent
@@ -1450,11 +1511,8 @@ extern "C" int ramx_dev_run_direction(ramx_dev *d, ramx_run_info *info)
     if (tracing)
     {
       // one row at a time: launch, wait, hand the row's trace to the caller (debugging aid, no attempt at speed)
-      const int B = 2 * a.W + 1;
-      int trc;
-      if ((trc = ensure(&d->d_dbg_codes, &d->cap_dbg_codes, (size_t)d->Np * B)) != RAMX_OK) return trc;
-      if ((trc = ensure(&d->d_dbg_best, &d->cap_dbg_best, (size_t)d->Np * sizeof(int2))) != RAMX_OK) return trc;
-      a.dbg_codes = d->d_dbg_codes; a.dbg_best = d->d_dbg_best;
+      int trc = trace_buffers(a);
+      if (trc != RAMX_OK) return trc;
       launch_column_trace(d, a);
       launches++;
       HIPCHK(hipGetLastError());
@@ -1462,18 +1520,7 @@ extern "C" int ramx_dev_run_direction(ramx_dev *d, ramx_run_info *info)
       RamxCtl c;
       HIPCHK(hipMemcpy(&c, a.ctl_out, sizeof(c), hipMemcpyDeviceToHost));
       if (c.rows_done == r + 1)      // the launch ran (a stopped predecessor makes the kernel return at once)
-      {
-        std::vector<int8_t> codes((size_t)d->Nx * B + 1);
-        std::vector<int2> best((size_t)d->Nx + 1);
-        std::vector<int32_t> bs((size_t)d->Nx + 1), bi((size_t)d->Nx + 1);
-        if (d->Nx)
-        {
-          HIPCHK(hipMemcpy(codes.data(), d->d_dbg_codes, (size_t)d->Nx * B, hipMemcpyDeviceToHost));
-          HIPCHK(hipMemcpy(best.data(), d->d_dbg_best, (size_t)d->Nx * sizeof(int2), hipMemcpyDeviceToHost));
-        }
-        for (int i = 0; i < d->Nx; i++) { bs[i] = best[i].x; bi[i] = best[i].y; }
-        d->trace_cb(r, c.besta, codes.data(), bs.data(), bi.data(), d->trace_user);
-      }
+        if ((trc = deliver_trace(r, c.besta)) != RAMX_OK) return trc;
       if (c.stopped) stopped = true;
       continue;
     }
@@ -1613,6 +1660,15 @@ extern "C" int ramx_dev_set_row_trace(ramx_dev *d, ramx_row_trace_cb cb, void *u
   if (!d) return RAMX_ERR_NO_DEVICE;
   d->trace_cb = cb;
   d->trace_user = user;
+  return RAMX_OK;
+}
+
+extern "C" int ramx_dev_set_row_verbose(ramx_dev *d, ramx_row_verbose_cb cb, void *user)
+{
+  if (!d) d = ramx_default_device();
+  if (!d) return RAMX_ERR_NO_DEVICE;
+  d->verbose_cb = cb;
+  d->verbose_user = user;
   return RAMX_OK;
 }
 

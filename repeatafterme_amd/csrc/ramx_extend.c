@@ -122,6 +122,73 @@ struct trace_ctx
 };
 static FILE *g_trace_file = NULL;
 
+/* ---- -vvvv: the reference's per-row lines (ram_extend.c:992-1090 candidate passes, 1134-1214 after the winner's pass), written
+ * from what the device reports for every launch: the four candidate rows of the NEXT row (best cell, its band cell, gap state of
+ * the first / last cell) and the winner row's best cell and end-cell gap states.  All sums in `int`, as the reference's. */
+struct verbose_ctx
+{
+  int direction, W, cap, minimp, nx;
+  const int32_t *core_index;       /* flank -> position of its core in the list (the reference's n) */
+  int *high;                       /* overall_sequence_high_score per flank */
+  int32_t *cand_prev;              /* [nx][16]: the candidate rows of the row about to be reported */
+  int max_ext, max_row;
+};
+
+static void verbose_row(int32_t row, int32_t besta, int32_t n_flanks, const int32_t *best_score, const int32_t *best_idx,
+                        const int32_t *gfl, const int32_t *cand, void *user)
+{
+  struct verbose_ctx *t = (struct verbose_ctx *)user;
+  static const char base[4] = { 'A', 'C', 'G', 'T' };
+  (void)besta; (void)best_idx;
+  const int nx = n_flanks < t->nx ? n_flanks : t->nx;
+  if (row >= 0)
+  {
+    int curr = 0, chosen = 0;
+    for (int a = 0; a < 4; a++)
+    {
+      int sum = 0;
+      for (int i = 0; i < nx; i++)
+      {
+        const int32_t *c = t->cand_prev + (size_t)i * 16;
+        printf(t->direction ? "RIGHT ROW %d with '%c': n = %d\n" : "LEFT ROW %d with '%c': n = %d\n", row, base[a], t->core_index[i]);
+        int b = c[a];
+        const int col = row + c[4 + a] - t->W, hi = t->high[i];
+        if (b < 0) printf("  best score = %d @ column %d -- max(0,best_score) = 0!, prev best score = %d\n", b, col, hi);
+        else printf("  best score = %d @ column %d, prev best score = %d\n", b, col, hi);
+        if ((t->direction && c[8 + a] < -279000) || (!t->direction && c[12 + a] < -279000)) printf(" **OUT_OF_SEQ**");
+        if (b < 0) b = 0;
+        if (b >= hi + t->cap) sum += b;
+        else { printf(" **CAPPED** contributing = %d", hi + t->cap); sum += hi + t->cap; }
+        printf("\n");
+      }
+      printf("  Total Score for '%c' = %d\n", base[a], sum);
+      if (sum > curr) { curr = sum; chosen = a; }
+    }
+    printf("ROW %d complete, '%c' chosen as the consensus. curr_ext_score = %d\n", row, base[chosen], curr);
+    int num_out = 0, num_high = 0;
+    for (int i = 0; i < nx; i++)
+    {
+      if ((!t->direction && gfl[2 * i] < -279000) || (t->direction && gfl[2 * i + 1] < -279000)) num_out++;
+      if (best_score[i] > t->high[i]) { t->high[i] = best_score[i]; num_high++; }
+    }
+    float since = 0.0f;
+    if (abs(row - t->max_row) > 0) since = ((float)(curr - t->max_ext) / abs(row - t->max_row));
+    printf("Alignment Extension: curr_extension_score = %d, max_extension_score = %d @ row %d\n                     "
+           "score_per_position_overall = %0.1f, score_per_position_since_max = %0.1f\n"
+           "                     total_edges = %d, num_extending = %d, num_out_of_seq = %d\n",
+           curr, t->max_ext, t->max_row, ((float)curr / (row + 1)), since, nx, num_high, num_out);
+    if (curr >= t->max_ext + (abs(t->max_row - row) * t->minimp))
+    {
+      printf("                     **This row is now the new max**\n");
+      t->max_row = row;
+      t->max_ext = curr;
+    }
+    else
+      printf("                     extensions since last max score %d\n", abs(row - t->max_row));
+  }
+  memcpy(t->cand_prev, cand, sizeof(int32_t) * 16 * (size_t)nx);
+}
+
 static char trace_num_to_char(int8_t z)      /* sequence.c:1091-1111 */
 {
   static const char t[8] = { 'A', 'C', 'G', 'T', 'a', 'c', 'g', 't' };
@@ -257,7 +324,19 @@ static int extend_flat_impl(int direction, ramx_flat_cores *c, const int8_t *seq
     tctx.cores = c; tctx.sequence = sequence; tctx.packed = packed;
     ramx_dev_set_row_trace(d, trace_row, &tctx);
   }
-  if (g_trace_file == NULL && nx > 0 && nx <= ramx_dev_family_route_max(d, p) && L > 0 && W >= 1 && getenv("RAMX_NO_FAMILY_ROUTE") == NULL)
+  /* -vvvv and above: the per-row lines of the reference, one column launch at a time */
+  struct verbose_ctx vctx;
+  memset(&vctx, 0, sizeof(vctx));
+  const int verbose_rows = g_verbose >= 10;
+  if (verbose_rows)
+  {
+    vctx.direction = direction; vctx.W = W; vctx.cap = p->cappenalty; vctx.minimp = p->minimprovement; vctx.nx = nx; vctx.core_index = map;
+    vctx.high = (int *)calloc((size_t)(nx > 0 ? nx : 1), sizeof(int));
+    vctx.cand_prev = (int32_t *)calloc((size_t)(nx > 0 ? nx : 1) * 16, sizeof(int32_t));
+    vctx.max_ext = 0; vctx.max_row = -1;
+    ramx_dev_set_row_verbose(d, verbose_row, &vctx);
+  }
+  if (g_trace_file == NULL && !verbose_rows && nx > 0 && nx <= ramx_dev_family_route_max(d, p) && L > 0 && W >= 1 && getenv("RAMX_NO_FAMILY_ROUTE") == NULL)
   {
     /* a family that fits one workgroup needs no device-wide barrier: run it as a batch of one (block-local vote) */
     const int npad = (nx + 63) & ~63;
@@ -280,6 +359,7 @@ static int extend_flat_impl(int direction, ramx_flat_cores *c, const int8_t *seq
     if (rc == RAMX_OK) rc = ramx_dev_run_direction(d, info);
     SEAM1_PHASE("run direction");
     if (g_trace_file != NULL) ramx_dev_set_row_trace(d, NULL, NULL);
+    if (verbose_rows) { ramx_dev_set_row_verbose(d, NULL, NULL); free(vctx.high); free(vctx.cand_prev); vctx.high = NULL; vctx.cand_prev = NULL; }
     if (rc != RAMX_OK) { free(cons); free(map); free(fl); return rc; }
     th = (int32_t *)malloc(sizeof(int32_t) * (nx > 0 ? nx : 1));
     tp = (int32_t *)malloc(sizeof(int32_t) * (nx > 0 ? nx : 1));
@@ -329,8 +409,9 @@ int ramx_extend_alignment(int direction, struct coreAlignment *coreAlign, int **
     if (direction) printf("extend_alignment(right): Called with %d edges\n", N);
     else printf("extend_alignment(left): Called with %d edges\n", N);
   }
-  if (g_verbose >= 10)
-    fprintf(stderr, "RAMExtend(ramx): per-row dumps of -vvvv and above are not produced by the device path\n");
+  if (g_verbose >= 12)
+    fprintf(stderr, "RAMExtend(ramx): the band dumps of -vvvvv and above (ram_extend.c:949-959, 1013-1024) are not produced by the "
+                    "device path; the per-row lines of -vvvv are\n");
 
   const int n = N > 0 ? N : 0;
   int64_t *i64 = (int64_t *)malloc(sizeof(int64_t) * 4 * (n + 1));

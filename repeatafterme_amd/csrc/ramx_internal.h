@@ -33,6 +33,15 @@ int ramx_host_threads(long items, long min_items_per_thread);
 typedef void (*ramx_chunk_fn)(int lo, int hi, FILE **outs, void *user);
 void ramx_parallel_chunks(int n, int n_outs, FILE **real_outs, ramx_chunk_fn fn, void *user);
 
+/* -vvvv support (reference ram_extend.c:992-1090, 1134-1214): with this callback set a direction runs one column launch at a
+ * time (full candidate recurrence) and hands over, after the boundary launch (row = -1) and after every executed row: per
+ * flank the winner row's best score / index / gap state of its first and last cell (row >= 0), and the four candidate rows
+ * row + 1: cand[i][16] = best[4], best cell[4], gap of the first cell[4], gap of the last cell[4].  d == NULL: seam 1's
+ * session.  A debugging aid: slow by construction. */
+typedef void (*ramx_row_verbose_cb)(int32_t row, int32_t besta, int32_t n_flanks, const int32_t *best_score, const int32_t *best_idx,
+                                    const int32_t *gap_first_last /* [n][2] */, const int32_t *cand /* [n][16] */, void *user);
+int ramx_dev_set_row_verbose(ramx_dev *d, ramx_row_verbose_cb cb, void *user);
+
 /* process-wide device session used by seam 1 (created on first use) */
 ramx_dev *ramx_default_device(void);
 

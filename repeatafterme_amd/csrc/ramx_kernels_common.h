@@ -43,6 +43,11 @@ struct KArgs
   // (0 substitution, 1 deletion, 2 insertion: bnw_extend.c:1027-1044), per flank the row's best score and cell
   signed char *dbg_codes;    // [Np][2W+1]
   int2 *dbg_best;            // [Np]
+  // -vvvv trace (DBG + CHAIN instantiations): per flank the four candidate rows r+1 as the reference's per-candidate
+  // compute_nw_row calls see them (ram_extend.c:992-1062) -- best cell value, its band cell, and the gap state of the row's
+  // first and last cell (the **OUT_OF_SEQ** tests of :1036-1038 and :1134-1136) -- and the same two gap states of row r
+  int *dbg_cand;             // [Np][16]: best[4], cell[4], gap_first[4], gap_last[4]; NULL: not wanted
+  int2 *dbg_gap;             // [Np]: gap state of row r's first / last cell
 };
 
 struct FamDesc { int tile0, ntiles, nx, id; };      // first 64-flank tile, tiles, flanks of the family; its index in the caller's arrays
@@ -259,6 +264,8 @@ struct LaneDP
   int bestF, jbest;
   int eA[4];     // CHAIN only: e of the candidates' previous cell
   int bestA[4];
+  // -vvvv trace only (DBG && CHAIN): where each candidate row's best cell is, gap states of the rows' end cells
+  int jA[4], gA0[4], gAL[4], gF0, gFL;
 };
 
 // Uniform (scalar) per-step quantities.
@@ -332,7 +339,12 @@ __device__ __forceinline__ void band_step(const int go, const int ge, const int 
       }
     }
     m = imax(sub, gap);                            // :1015-1018
-    if (DBG && !INIT)
+    if (DBG && CHAIN)
+    {
+      if (u.j == 0) L.gF0 = gap;
+      if (u.j == 2 * W) L.gFL = gap;
+    }
+    if (DBG && !INIT && code != nullptr)
     {
       // which state the reference's path string reports for this cell (:1038-1043): the substitution if it holds the
       // cell's score, else the deletion if it does, else the insertion; out-of-bounds cells have all three equal
@@ -373,6 +385,13 @@ __device__ __forceinline__ void band_step(const int go, const int ge, const int 
     {
       const int subA = mSel + sv[c];
       const int gapA = imed3(L.eA[c], lo, hi);     // in bounds: max(ins, del); masked: vC
+      if (DBG && !u.first)
+      {
+        // candidate cell j-1 of row r+1: strict > keeps the lowest cell on ties (bnw_extend.c:1020-1024)
+        if (imax(subA, gapA) > L.bestA[c]) L.jA[c] = u.j - 1;
+        if (u.j - 1 == 0) L.gA0[c] = gapA;
+        if (u.j - 1 == 2 * W) L.gAL[c] = gapA;
+      }
       L.bestA[c] = imax3(L.bestA[c], subA, gapA);
       L.eA[c] = imax(subA + go, gapA) + ge;
     }
@@ -444,7 +463,7 @@ __device__ __forceinline__ void run_band(const KArgs &a, const int r, const int 
     int m0, e0, m1, e1;
     // cell B-1 has no deletion predecessor (bnw_extend.c:892); then the virtual step j = B
     band_step<INIT, true, OOB, CHAIN, DBG>(go, ge, W, make_u(2 * W), t0, cur.x, NEG, D, m0, e0, code);
-    band_step<INIT, false, OOB, CHAIN>(go, ge, W, make_u(B), t1, 0, 0, D, m1, e1);
+    band_step<INIT, false, OOB, CHAIN, DBG>(go, ge, W, make_u(B), t1, 0, 0, D, m1, e1, code);
     if (!INIT)
     {
       high = cur.z; pos = cur.w;

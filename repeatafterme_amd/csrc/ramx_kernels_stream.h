@@ -104,14 +104,22 @@ __global__ __launch_bounds__(BLOCK) void ramx_column_kernel(const KArgs a)
     LaneDP D;
     D.eC = NEG; D.mPrev = NEG - 1000000; D.bestF = NEG; D.jbest = 0;
 #pragma unroll
-    for (int c = 0; c < 4; c++) { D.eA[c] = NEG; D.bestA[c] = NEG; }
+    for (int c = 0; c < 4; c++) { D.eA[c] = NEG; D.bestA[c] = NEG; D.jA[c] = 0; D.gA0[c] = NEG; D.gAL[c] = NEG; }
+    D.gF0 = NEG; D.gFL = NEG;
     int high = 0, pos = 0;
     // wave-uniform choice: do all 64 flanks cover every cell of both rows?  (steps 0..B)
     const bool all_in = !INIT && !DBG && __all((n >= a.Nx) || ((jlo <= 0) && (jhi >= B)));   // padding lanes: all-N stream, masked vote
     if (all_in) run_band<INIT, false, CHAIN>(a, r, s_tab, Sin, Sout, bp, jlo, jhi, D, high, pos, buf, far, w0, w1, w2);
     else run_band<INIT, true, CHAIN, DBG>(a, r, s_tab, Sin, Sout, bp, jlo, jhi, D, high, pos, buf, far, w0, w1, w2,
-                                          DBG ? a.dbg_codes + (size_t)n * B : nullptr);
-    if (DBG && !INIT) a.dbg_best[n] = make_int2(D.bestF, r + D.jbest - W);   // best_row_score, *max_score_sequence_idx
+                                          (DBG && a.dbg_codes != NULL) ? a.dbg_codes + (size_t)n * B : nullptr);
+    if (DBG && !INIT && a.dbg_best != NULL) a.dbg_best[n] = make_int2(D.bestF, r + D.jbest - W);   // best_row_score, *max_score_sequence_idx
+    if (DBG && CHAIN && a.dbg_cand != NULL)
+    {
+      int *o = a.dbg_cand + (size_t)n * 16;
+#pragma unroll
+      for (int c = 0; c < 4; c++) { o[c] = D.bestA[c]; o[4 + c] = D.jA[c]; o[8 + c] = D.gA0[c]; o[12 + c] = D.gAL[c]; }
+      a.dbg_gap[n] = make_int2(D.gF0, D.gFL);
+    }
     if (INIT || new_max) a.trim[n] = make_int2(high, pos);   // ram_extend.c:1203-1207 (913-914 at init)
     if (n < a.Nx)
     {

@@ -91,6 +91,33 @@ def outmat_traces():
         print("outmat", case, data.count(b"\n"), "lines")
 
 
+# -vvvv: the per-row lines of ram_extend.c:992-1090 and 1134-1214 (candidate passes, **OUT_OF_SEQ**, **CAPPED**, totals, the
+# "Alignment Extension" block); the reference's whole stdout, gzip-compressed.  (case name, input stem, argv)
+VERBOSE_CASES = [
+    ("t2_vvvv", "extension-test2", ["-bandwidth", "5", "-L", "30", "-vvvv"]),
+    ("g3_vvvv", "genome_3", ["-bandwidth", "20", "-matrix", "14p43g", "-L", "60", "-vvvv"]),
+    ("ov_vvvv", "genome_ov", ["-L", "40", "-bandwidth", "14", "-vvvv", "-cappenalty", "-10"]),
+    ("g1_vvvv_rs", "genome_1", ["-matrix", "repeatscout", "-match", "2", "-mismatch", "-2", "-gap", "-6", "-L", "50", "-bandwidth", "10",
+                                "-vvvv"]),
+    ("g2_vvvv_w3", "genome_2", ["-bandwidth", "3", "-matrix", "18p43g", "-L", "80", "-cappenalty", "-40", "-vvvv"]),
+]
+
+
+def verbose_traces():
+    import gzip
+    for case, stem, argv in VERBOSE_CASES:
+        out = os.path.join(HERE, "cli", case)
+        os.makedirs(out, exist_ok=True)
+        cmd = [po.REF_CLI, "-twobit", f"inputs/{stem}.2bit", "-ranges", f"inputs/{stem}.tsv"] + argv
+        r = subprocess.run(cmd, cwd=HERE, capture_output=True, text=True)
+        assert r.returncode == 0, (cmd, r.stderr)
+        with gzip.GzipFile(os.path.join(out, "vvvv.gz"), "wb", mtime=0) as fh:
+            fh.write(r.stdout.encode())
+        open(os.path.join(out, "argv"), "w").write(" ".join(argv) + "\n")
+        open(os.path.join(out, "stem"), "w").write(stem + "\n")
+        print("vvvv", case, r.stdout.count("\n"), "lines")
+
+
 def api_vectors():
     """Reference results for in-memory sets (adversarial + two uniform families)."""
     data = {}
@@ -154,8 +181,13 @@ def main():
         run_cli(case, stem, argv)
         print("cli case", case)
     outmat_traces()
+    verbose_traces()
     api_vectors()
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "verbose":     # only the -vvvv traces (the other fixtures stay as they are)
+        assert po.have_ref() and os.path.exists(po.REF_CLI), "build oracle/_ref first (make -C oracle ref)"
+        verbose_traces()
+    else:
+        main()

@@ -10,7 +10,8 @@ from repeatafterme_amd import _lib
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = os.path.join(ROOT, "tests", "golden")
-CASES = sorted(os.listdir(os.path.join(G, "cli")))
+CASES = sorted(c for c in os.listdir(os.path.join(G, "cli")) if os.path.exists(os.path.join(G, "cli", c, "stdout")))
+VERBOSE = sorted(c for c in os.listdir(os.path.join(G, "cli")) if os.path.exists(os.path.join(G, "cli", c, "vvvv.gz")))
 STEM = {"t2": "extension-test2", "g0": "genome_0", "g1": "genome_1", "g2": "genome_2", "g3": "genome_3", "ov": "genome_ov"}
 
 
@@ -157,3 +158,24 @@ def test_reference_main_with_only_the_loop_replaced(case, tmp_path):
         ref_f = os.path.join(G, "cli", case, f)
         if os.path.exists(ref_f):
             assert open(tmp_path / f).read() == open(ref_f).read(), f
+
+
+@pytest.mark.parametrize("case", VERBOSE)
+def test_cli_vvvv_per_row_lines_match_reference(case):
+    """-vvvv: the reference's per-row lines (ram_extend.c:992-1090, 1134-1214) -- for every row, candidate base and
+    extendable core the candidate row's best score and column, `-- max(0,best_score) = 0!`, ` **OUT_OF_SEQ**`,
+    ` **CAPPED** contributing = ...`, the totals per candidate, the chosen base, and the "Alignment Extension" block with
+    its float columns and the new-maximum / extensions-since lines -- written from the device's candidate-row trace (full
+    recurrence).  Whole stdout against the reference binary's, both directions; five cases incl. short flanks
+    (OUT_OF_SEQ), a tight cap (CAPPED), repeatscout scoring and bandwidth 3."""
+    import gzip
+    argv = open(os.path.join(G, "cli", case, "argv")).read().split()
+    stem = open(os.path.join(G, "cli", case, "stem")).read().strip()
+    cmd = [_lib.CLI_PATH, "-twobit", f"inputs/{stem}.2bit", "-ranges", f"inputs/{stem}.tsv"] + argv
+    r = subprocess.run(cmd, cwd=G, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    want = gzip.open(os.path.join(G, "cli", case, "vvvv.gz"), "rb").read().decode()
+    g, w = _norm(r.stdout), _norm(want)
+    assert len(g) == len(w), (len(g), len(w))
+    for i, (a, b) in enumerate(zip(g, w)):
+        assert a == b, f"line {i}: {a!r} != {b!r}"
