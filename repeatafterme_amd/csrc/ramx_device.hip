@@ -160,7 +160,7 @@ extern "C" int ramx_dev_create(int ordinal, ramx_dev **out)
   CRCHK(hipHostMalloc((void **)&d->h_ctl, 4 * sizeof(RamxCtl), hipHostMallocDefault));
   CRCHK(hipMalloc((void **)&d->d_sums, (3 * NSHARD * 4 + 8) * sizeof(long long)));
   CRCHK(hipMalloc((void **)&d->d_ctl, 2 * sizeof(RamxCtl)));
-  CRCHK(hipMalloc((void **)&d->d_vote, RAMX_CP_NSETS * NSHARD * sizeof(PShard)));   // four rotating sets (both persistent kernels)
+  CRCHK(hipMalloc((void **)&d->d_vote, PRK_NSETS * NSHARD * sizeof(PShard)));   // four rotating vote sets (both persistent kernels)
   CRCHK(hipMalloc((void **)&d->d_err, 64));
 
   for (int i = 0; i < 2; i++) CRCHK(hipEventCreate(&d->ev_chk[i]));
@@ -568,6 +568,17 @@ static int fast_pack_ok(const int (&tab)[RAMX_NCLASS][4], int go, int ge, int L,
   return ((long long)L + 2LL * W + 4) * mx < (1LL << 27) ? 1 : 0;
 }
 
+// P of the LEAN test of the register-resident bands (ramx_kernels_resident.h, prk_band_fast): max(0, largest matrix entry);
+// -1 (never LEAN) with RAMX_NO_LEAN (A/B and tests) or when a gap penalty is positive
+static int lean_p_of(const int (&tab)[RAMX_NCLASS][4], int go, int ge)
+{
+  if (getenv("RAMX_NO_LEAN") != NULL || go > 0 || ge > 0) return -1;
+  int mx = 0;
+  for (int c = 0; c < RAMX_NCLASS; c++)
+    for (int k = 0; k < 4; k++) if (tab[c][k] > mx) mx = tab[c][k];
+  return mx;
+}
+
 // ---- persistent path --------------------------------------------------------------------------
 // Block shape of the persistent launch: at most ONE barrier participant per CU.
 //   <= 4 tiles per CU (N <= 65,536): 256-thread blocks, one wave per SIMD, up to 256 blocks;
@@ -708,7 +719,8 @@ static int prk_run(ramx_dev *d, const KArgs &a, int L, bool *used)
   memcpy(pa.tab, a.tab, sizeof(pa.tab));
   pa.pack_ok = getenv("RAMX_NO_FASTPACK") ? 0 : fast_pack_ok(pa.tab, a.go, a.ge, L, W);
   if (pa.pack_ok && getenv("RAMX_NO_MASKHI") == NULL) pa.pack_ok = 2;      // 2: the far-end-masked fast band may be used too
-  HIPCHK(hipMemsetAsync(d->d_vote, 0, RAMX_CP_NSETS * NSHARD * sizeof(PShard), d->stream));
+  pa.lean_p = lean_p_of(pa.tab, a.go, a.ge);
+  HIPCHK(hipMemsetAsync(d->d_vote, 0, PRK_NSETS * NSHARD * sizeof(PShard), d->stream));
   HIPCHK(hipMemsetAsync(d->d_err, 0, 64, d->stream));
 #ifdef RAMX_PRK_TIMING
   const size_t nw = (size_t)blocks * (block / 64);
@@ -766,6 +778,8 @@ static void cp_test_hooks(CPArgs &ca)
   ca.test_wrong_every = we ? atoi(we) : 0;
   ca.test_vote_delay = vd ? atoi(vd) : 0;
   ca.deep = (dp && atoi(dp) != 0) ? 1 : 0;
+  // (the barrier-free variant rewinds rows: its band waves would have to rewind the LEAN test's previous-row best too)
+  ca.lean_p = ca.deep ? -1 : lean_p_of(ca.tab, ca.go, ca.ge);
 }
 
 // ---- batch mode -------------------------------------------------------------------------------
@@ -934,6 +948,7 @@ static int run_families_pass(ramx_dev *d, const ramx_flank *flanks, int32_t n_pa
   memcpy(fa.tab, tab9, sizeof(fa.tab));
   fa.pack_ok = getenv("RAMX_NO_FASTPACK") ? 0 : fast_pack_ok(fa.tab, fa.go, fa.ge, L, W);
   if (fa.pack_ok && getenv("RAMX_NO_MASKHI") == NULL) fa.pack_ok = 2;
+  fa.lean_p = lean_p_of(fa.tab, fa.go, fa.ge);
 #ifdef RAMX_PRK_TIMING
   FAMCHK(hipMalloc((void **)&fa.dbg, 8 * 8 * sizeof(unsigned long long)));
   FAMCHK(hipMemset(fa.dbg, 0, 8 * 8 * sizeof(unsigned long long)));
@@ -1010,6 +1025,7 @@ static int run_families_pass(ramx_dev *d, const ramx_flank *flanks, int32_t n_pa
     ca.Np = Np; ca.KW = KW; ca.L = L; ca.go = p->gapopen; ca.ge = p->gapextn; ca.cap = p->cappenalty; ca.minimp = p->minimprovement;
     ca.when_to_stop = p->when_to_stop;
     memcpy(ca.tab, tab9, sizeof(ca.tab));
+    ca.lean_p = lean_p_of(ca.tab, ca.go, ca.ge);
     if (getenv("RAMX_CP_PEEK") != NULL)
     {
       // test hook: keep the final rows of every flank, [flank][2W+1] (m, e), for ramx_dev_peek_family_state

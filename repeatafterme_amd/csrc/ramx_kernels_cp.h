@@ -300,6 +300,42 @@ __device__ __forceinline__ void cp_update(const CpLane &ln, const int go, const 
 
 // Best cell of row r (value, lowest cell on ties: bnw_extend.c:1020-1024) and the best cells of the four candidate rows
 // r+1 (chain-free rule of ramx_kernels_common.h), reduced over the group: every lane returns the same values.
+// one value over the group (butterfly: every lane ends with the maximum)
+template <int K>
+__device__ __forceinline__ void cp_allmax1(int &a)
+{
+  if (K >= 2) CP_MAX1(a, CP_QP(1, 0, 3, 2), CP_FULL);
+  if (K >= 4) CP_MAX1(a, CP_QP(2, 3, 0, 1), CP_FULL);
+  if (K >= 8) CP_MAX1(a, "row_half_mirror", CP_FULL);
+  if (K >= 16) CP_MAX1(a, "row_mirror", CP_FULL);
+}
+
+// LEAN (in-bounds fast path only): the best VALUE of row r and nothing else -- no candidate rows, no index of the best cell.
+// Taken for a wave none of whose flanks can contribute more than its cap to the next vote or set a record in this row; the
+// proof is the one of ramx_kernels_resident.h (prk_band_fast): with go, ge <= 0 the best cell of row r is at most
+// P = max(0, largest matrix entry) above the best cell of row r-1 and every candidate row r+1 at most 2P above it.
+template <int W, int K>
+__device__ __forceinline__ void cp_reduce_lean(const CpLane &ln, const int (&m)[CpCfg<W, K>::C], int &bestF, int &jbest, int (&bestA)[4])
+{
+  typedef CpCfg<W, K> Cfg;
+  constexpr int C = Cfg::C, IB = Cfg::IB;
+  int kb = CP_IMIN, kp = CP_IMIN;
+  static_for([&](auto ic) __attribute__((always_inline))
+  {
+    constexpr int i = decltype(ic)::value;
+    int key = m[i];
+    if constexpr (i > IB) key = ln.pFull ? key : CP_IMIN;         // dead cells of the lane that holds cell 2W
+    if constexpr ((i & 1) == 0 && i + 1 < C) kp = key;
+    else if constexpr ((i & 1) != 0) kb = imax3(kb, kp, key);
+    else kb = imax(kb, key);
+  }, std::make_integer_sequence<int, C>{});
+  kb = ln.pDead ? CP_IMIN : kb;
+  cp_allmax1<K>(kb);
+  bestF = kb;
+  jbest = 0;
+  bestA[0] = bestA[1] = bestA[2] = bestA[3] = CP_IDN;
+}
+
 template <int W, int K, bool G>
 __device__ __forceinline__ void cp_reduce(const CpLane &ln, const CpTabs &tabs, const unsigned (&AE)[CpCfg<W, K>::NA],
                                           const unsigned (&AO)[CpCfg<W, K>::NA], const int (&m)[CpCfg<W, K>::C],
@@ -787,6 +823,7 @@ void ramx_cp_kernel(const CPArgs a)
   asm volatile("" : "+v"(vgo), "+v"(vge));
   int m[C], e[C];
   int high = 0, pos = 0, thigh = 0, tpos = 0;
+  int prevBest = 0x3fffffff;           // best cell of the previous FINAL row (LEAN test in band()): unknown at first
   const int2 bd = a.bounds[n];
 
   // base words: the lane's window covers nibbles s .. s+C, s = j0 + r + 8; w[k] = word (s >> 3) + k, one word ahead
@@ -1041,7 +1078,16 @@ void ramx_cp_kernel(const CPArgs a)
     };
     cp_update<W, K, G>(ln, vgo, vge, a.go + (r + 1) * a.ge /* edge fill, first W rows only (set_masks: iWr) */, sf, m, e);
     CP_TICK(2);                  // row update
-    cp_reduce<W, K, G>(ln, sm.tabs, AE, AO, m, e, bestF, jb, bestA);
+    if constexpr (!G)
+    {
+      // LEAN: no flank of the wave can contribute more than its cap to the next vote or set a record in this row
+      // (prevBest: best cell of row r-1; `high` before this row's record update: the cap only grows)
+      const int capfloor = (high + a.cap) > 0 ? (high + a.cap) : 0;
+      const bool lean = a.lean_p >= 0 && __all(!active || ((prevBest + 2 * a.lean_p <= capfloor) && (prevBest + a.lean_p <= high)));
+      if (lean) cp_reduce_lean<W, K>(ln, m, bestF, jb, bestA);
+      else cp_reduce<W, K, false>(ln, sm.tabs, AE, AO, m, e, bestF, jb, bestA);
+    }
+    else cp_reduce<W, K, G>(ln, sm.tabs, AE, AO, m, e, bestF, jb, bestA);
     CP_TICK(3);                  // reductions
   };
   // ---- the band waves ---------------------------------------------------------------------------------------------------
@@ -1424,6 +1470,7 @@ void ramx_cp_kernel(const CPArgs a)
 #endif
       }
       high = high1; pos = pos1;
+      prevBest = bestF;          // of the row as it stands now (speculative pass accepted, or recomputed)
       if (new_max) { thigh = high; tpos = pos; }                 // :1203-1207
       slide_window();
       window_words(AE, AO);      // next column's window
@@ -1498,6 +1545,7 @@ void ramx_cp_kernel(const CPArgs a)
     if (live)
     {
       band(r, besta, gc, bestF, jb, bestA);
+      prevBest = bestF;
       if (bestF > high) { high = bestF; pos = r + jb - W; }      // ram_extend.c:1140-1150
       if (new_max) { thigh = high; tpos = pos; }                 // :1203-1207
       finish_column(bestA, contrib);

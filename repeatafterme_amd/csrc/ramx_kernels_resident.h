@@ -34,6 +34,7 @@
 // launches when that happens (ramx_dev_run_direction; batch mode: ramx_dev_run_families repeats the affected
 // families).  Multi-GPU runs exchange the vote through the mailboxes below, or fall back to RCCL between per-column launches.
 
+#define PRK_NSETS 4        // rotating vote sets: row r uses set r % 4, block 0 clears the set of row r+3 in column r (protocol above)
 #ifndef PRK_SHARD_BYTES
 #define PRK_SHARD_BYTES 256   // 64 (one line per shard) measured 1.5-2 % slower: neighbouring shards share a memory channel
 #endif
@@ -97,6 +98,7 @@ struct PArgs
   int Np, Nx, r0, L, go, ge, cap, minimp, when_to_stop, nblocks;
   int tab[RAMX_NCLASS][4];
   int pack_ok;                  // every reachable score fits 27 bits: the fast path may pack (score, cell) keys
+  int lean_p;                   // P = max(0, largest matrix entry) of the LEAN test (prk_band_fast); -1: never LEAN
   unsigned long long *dbg;      // -DRAMX_PRK_TIMING builds only: [block][8] phase sums in 10 ns ticks
 };
 
@@ -119,6 +121,9 @@ struct PArgs
 #endif
 #ifndef PRK_FETCH_AHEAD
 #define PRK_FETCH_AHEAD 2
+#endif
+#ifndef PRK_FETCH_AHEAD_LEAN
+#define PRK_FETCH_AHEAD_LEAN 2        // the LEAN band has registers to spare: table rows fetched further ahead
 #endif
 __device__ __forceinline__ int vmax3(int x, int y, int z)   // forced v_max3_i32 (keeps the compiler from re-associating)
 {
@@ -178,6 +183,21 @@ __device__ __forceinline__ int add_sext_byte(int x, int packed)   // x + (int)(s
   return d;
 }
 
+template <int HALF>
+__device__ __forceinline__ int add_sext_word(int x, int packed)   // x + (int)(short)(packed >> 16*HALF)
+{
+  int d;
+  if (HALF == 0) asm("v_add_u32_sdwa %0, %1, sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(d) : "v"(x), "v"(packed));
+  else asm("v_add_u32_sdwa %0, %1, sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(d) : "v"(x), "v"(packed));
+  return d;
+}
+__device__ __forceinline__ int pack_halves(int lo, int hi)         // (lo & 0xffff) | (hi << 16)
+{
+  int d;
+  asm("v_perm_b32 %0, %1, %2, %3" : "=v"(d) : "v"(hi), "v"(lo), "s"(0x05040100));
+  return d;
+}
+
 // candidate bytes: once per launch.
 template <int BLOCK>
 __device__ __forceinline__ void fast_tabs_init(FastTabs &ft, const int (&tab)[RAMX_NCLASS][4])
@@ -209,7 +229,17 @@ __device__ __forceinline__ void fast_tabs_winner(FastTabs &ft, const int *tab_be
 // cells store (SENT, SENT + ge) exactly as the general band does; their candidate terms only have to stay negative
 // (the vote clamps at 0, ram_extend.c:1042) and their keys below every positive score (the best cell only matters when
 // it beats high >= 0): five extra VALU per cell instead of the general band's separate formulation.
-template <int W, int BLOCK, bool MASKHI>
+//
+// LEAN: the same row update WITHOUT the four candidate rows and without the best cell's index, for a wave whose lanes can
+// neither contribute anything but their cap to the next vote nor set a record in this row.  With go, ge <= 0 every cell of a
+// row is at most P = max(0, largest matrix entry) above the best cell of the row before, so with prevBest = best cell of row
+// r-1:  best cell of row r <= prevBest + P,  best cell of any candidate row r+1 <= prevBest + 2P.  If
+//     prevBest + 2P <= max(0, high + CAPPENALTY)   and   prevBest + P <= high      for every lane of the wave,
+// then max(0, candidate best) never exceeds max(0, high + cap) -- the contribution is max(0, high + cap) whatever the candidate
+// rows hold (ram_extend.c:1042, 1052-1062) -- and `best > high` (:1140) is false: only the row itself (and its best VALUE,
+// for the next row's test) has to be computed.  That is every column behind the end of the alignment, where flanks sit at
+// their cap: ~9 instead of ~16.5 VALU per cell.  Exact, not an approximation: the skipped values cannot influence any output.
+template <int W, int BLOCK, bool MASKHI, bool LEAN = false>
 __device__ __forceinline__ void prk_band_fast(const int go_, const int ge_, const FastTabs &ft, short *sD, const int r, const int jhi,
                                               const unsigned (&w)[(2 * W + 1 + 8) / 8 + 2], int (&M)[2 * W + 1], LaneDP &D)
 {
@@ -234,10 +264,14 @@ __device__ __forceinline__ void prk_band_fast(const int go_, const int ge_, cons
   // compile-time cell index: the band is generated step by step (no reliance on the loop unroller, whose size limit
   // would otherwise leave the row in scratch memory).  Table rows and the previous row's e are fetched PD steps ahead
   // of their use (a lone wave per SIMD -- one family per workgroup -- has nobody to hide the LDS latency behind).
-  constexpr int PD = PRK_FETCH_AHEAD;
+  constexpr int PD = LEAN ? PRK_FETCH_AHEAD_LEAN : PRK_FETCH_AHEAD;
   unsigned A = 0, Alo = 0;
   int2 rowQ[PD];                                    // {candidate bytes, M[besta][base]} of steps j .. j+PD-1
-  int dQ[PD];                                       // e - m of the previous row's cells j+1 .. j+PD
+  // e - m of the previous row, TWO cells per LDS instruction: a lane's dword of cell pair p holds d[2p] | d[2p+1] << 16
+  // (the layout the int16 accesses of the other bands use too).  dCurW: pair of the cell whose d this step needs (cell j+1),
+  // dNxtW: the pair after it, loaded one pair ahead of its first use; the new row's d is written a pair at a time as well.
+  int dCurW = 0, dNxtW = 0, dLo = 0;
+  int *myDW = reinterpret_cast<int *>(sD) + threadIdx.x;
   auto fetch_row = [&](auto jc) __attribute__((always_inline))
   {
     constexpr int jn = decltype(jc)::value;         // the step whose base is looked up
@@ -250,15 +284,17 @@ __device__ __forceinline__ void prk_band_fast(const int go_, const int ge_, cons
     unsigned off;
     if constexpr ((jn & 1) == 0) off = nib_lo_x16<byte>(Alo);
     else off = nib_hi_x16<byte>(A, mask_f0);
-    return *reinterpret_cast<const int2 *>(tb + off);
+    if constexpr (LEAN) return make_int2(0, *reinterpret_cast<const int *>(tb + off + 4));    // the winner's score only
+    else return *reinterpret_cast<const int2 *>(tb + off);
   };
   static_for([&](auto kc) __attribute__((always_inline))
   {
     constexpr int k = decltype(kc)::value;
     if constexpr (k <= B) rowQ[k] = fetch_row(std::integral_constant<int, (k <= B ? k : 0)>{});
     else rowQ[k] = make_int2(0, 0);
-    dQ[k] = (k + 1 < B) ? (int)myD[((k + 1) >> 1) * (2 * BLOCK) + ((k + 1) & 1)] : 0;
   }, std::make_integer_sequence<int, PD>{});
+  dCurW = myDW[0];                                   // pair 0: cell 1 is step 0's deletion predecessor
+  if constexpr (B > 2) dNxtW = myDW[BLOCK];          // pair 1
   auto step = [&](auto jc) __attribute__((always_inline))
   {
     constexpr int j = decltype(jc)::value;
@@ -270,14 +306,18 @@ __device__ __forceinline__ void prk_band_fast(const int go_, const int ge_, cons
       __builtin_amdgcn_sched_barrier(0);
     }
     const int sv = rowQ[0].x, sF = rowQ[0].y;
-    const int dCur = dQ[0];
 #pragma unroll
-    for (int k = 0; k + 1 < PD; k++) { rowQ[k] = rowQ[k + 1]; dQ[k] = dQ[k + 1]; }
+    for (int k = 0; k + 1 < PD; k++) rowQ[k] = rowQ[k + 1];
     if constexpr (j + PD <= B) rowQ[PD - 1] = fetch_row(std::integral_constant<int, (j + PD <= B ? j + PD : 0)>{});
-    if constexpr (j + PD + 1 < B) dQ[PD - 1] = (int)myD[((j + PD + 1) >> 1) * (2 * BLOCK) + ((j + PD + 1) & 1)];
+    // cell j+1 is the first cell of pair (j+1)/2 when j is odd: move on to the pair loaded two steps ago, load the next one
+    if constexpr ((j & 1) != 0 && j + 1 < B)
+    {
+      dCurW = dNxtW;
+      if constexpr (((j + 1) >> 1) + 1 <= (B - 1) / 2) dNxtW = myDW[(((j + 1) >> 1) + 1) * BLOCK];
+    }
     const bool inb = MASKHI ? (j <= jhi) : true;     // this step's cell of row r and candidate cell j-1 of row r+1
     // candidates' cell j-1 of row r+1: substitution from m_{j-1} of row r (the base of that cell is this step's)
-    if constexpr (j >= 1)
+    if constexpr (j >= 1 && !LEAN)
     {
       const int ms = MASKHI ? (inb ? mPrev : SENT) : mPrev;
       const int t4[4] = { add_sext_byte<0>(ms, sv), add_sext_byte<1>(ms, sv), add_sext_byte<2>(ms, sv), add_sext_byte<3>(ms, sv) };
@@ -296,21 +336,25 @@ __device__ __forceinline__ void prk_band_fast(const int go_, const int ge_, cons
     {
       const int Pm = M[j];
       int Pe = NEG;
-      if constexpr (j + 1 < B) Pe = M[j + 1] + dCur;
+      if constexpr (j + 1 < B) Pe = add_sext_word<((j + 1) & 1)>(M[j + 1], dCurW);
       const int sub = Pm + sF;                       // bnw_extend.c:950-956
       const int mr = vmax3(sub, eC, Pe);             // max(sub, max(ins, del)), :1007-1018
       const int er = vmax3(sub + go, eC, Pe) + ge;
       const int m = MASKHI ? (inb ? mr : SENT) : mr;                 // :990-1002
       const int e = MASKHI ? (inb ? er : SENT + ge) : er;            // max(SENT + go, SENT) + ge with go <= 0
       M[j] = m;
-      myD[(j >> 1) * (2 * BLOCK) + (j & 1)] = (short)(e - m);
-      const int kr = (int)(((unsigned)mr << 4) | (unsigned)(15 - (j & 15)));
+      if constexpr ((j & 1) == 0 && j + 1 < B) dLo = e - m;
+      else if constexpr ((j & 1) != 0) myDW[(j >> 1) * BLOCK] = pack_halves(dLo, e - m);
+      else myD[(j >> 1) * (2 * BLOCK)] = (short)(e - m);           // cell 2W: the low half of the last pair
+      // best cell: packed (value, cell) keys -- LEAN: the value alone (kg[0] is then a plain running maximum of m)
+      const int kr = LEAN ? mr : (int)(((unsigned)mr << 4) | (unsigned)(15 - (j & 15)));
       const int key = MASKHI ? (inb ? kr : -2147483647 - 1) : kr;
+      constexpr int gk = LEAN ? 0 : (j >> 4);
       if constexpr ((j & 1) == 0 && j + 1 < B) kPend = key;
-      else if constexpr ((j & 1) != 0) kg[j >> 4] = imax3(kg[j >> 4], kPend, key);
-      else kg[j >> 4] = imax(kg[j >> 4], key);
+      else if constexpr ((j & 1) != 0) kg[gk] = imax3(kg[gk], kPend, key);
+      else kg[gk] = imax(kg[gk], key);
       // deletion term of candidate cell j-1 is e_j (cells 1..B-1)
-      if constexpr (j >= 1)
+      if constexpr (j >= 1 && !LEAN)
       {
         if constexpr ((j & 1) != 0) ePend = e;
         else maxE = imax3(maxE, ePend, e);
@@ -320,6 +364,15 @@ __device__ __forceinline__ void prk_band_fast(const int go_, const int ge_, cons
     }
   };
   static_for(step, std::make_integer_sequence<int, B + 1>{});
+  if constexpr (LEAN)
+  {
+    // no candidate rows: the caller has proved that the contribution is max(0, high + cap) whatever they hold
+#pragma unroll
+    for (int c = 0; c < 4; c++) D.bestA[c] = NEG;
+    D.bestF = kg[0];
+    D.jbest = 0;
+    return;
+  }
   // B is odd: the last candidate term (step B) is still pending; B-1 is even: every e has been folded
 #pragma unroll
   for (int c = 0; c < 4; c++) D.bestA[c] = imax3(bA[c], (B & 1) ? pend[c] : NEG, maxE);
@@ -415,6 +468,8 @@ __global__ __launch_bounds__(BLOCK, 2) void ramx_persistent_kernel(const PArgs a
   // ---- row state -> registers (m) and LDS (e - m) -----------------------------------------
   int M[B];
   int high, pos, thigh = 0, tpos = 0;
+  int prevBest = 0x3fffffff;             // best cell of the previous row (LEAN test): unknown before the first band of this launch
+  bool lean_now = false;                 // this wave runs the LEAN band in the column that is about to start
   {
 #pragma unroll
     for (int q = 0; q < W; q++)
@@ -470,7 +525,7 @@ __global__ __launch_bounds__(BLOCK, 2) void ramx_persistent_kernel(const PArgs a
         // lane = shard + 32 * half polls words 2*half, 2*half+1 of "its" shard: one 16-byte load per lane and round
         // (a quarter of the requests of four 8-byte loads on 32 lanes; the poll competes with the adds it waits for)
         const int sidx = lane & (NSHARD - 1), half = lane >> 5;
-        const unsigned long long *src = &a.vote[(size_t)(r & 3) * NSHARD + sidx].word[2 * half];
+        const unsigned long long *src = &a.vote[(size_t)(r & (PRK_NSETS - 1)) * NSHARD + sidx].word[2 * half];
         unsigned spins = 0;
         bool done = my_shard_blocks <= 0 || (a.nranks > 1 && blockIdx.x != 0);   // multi-rank: only the exchanger needs the local total
         unsigned long long x0 = 0, x1 = 0;
@@ -601,7 +656,7 @@ __global__ __launch_bounds__(BLOCK, 2) void ramx_persistent_kernel(const PArgs a
     // block 0 clears the vote set of row r+3 (see the protocol above)
     if (blockIdx.x == 0 && threadIdx.x < NSHARD)
     {
-      PShard *z = a.vote + (size_t)((r + 3) & 3) * NSHARD + threadIdx.x;
+      PShard *z = a.vote + (size_t)((r + 3) & (PRK_NSETS - 1)) * NSHARD + threadIdx.x;
 #pragma unroll
       for (int k = 0; k < 4; k++) __hip_atomic_store(&z->word[k], 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -619,12 +674,34 @@ __global__ __launch_bounds__(BLOCK, 2) void ramx_persistent_kernel(const PArgs a
       // padding lanes (no flank: their base stream is all N, their vote is masked) must not force the whole wave onto
       // the masked path -- with N not a multiple of 64 that one slow wave would gate every column
       const bool all_in = a.pack_ok && __all((n >= a.Nx) || ((jlo <= 0) && (jhi >= B)));
-      if (all_in) prk_band<W, false, BLOCK>(a.go, a.ge, s_tab, s_ft, sD, r, w, jlo, jhi, M, D);
-      else if (a.pack_ok > 1 && r >= W && __all((n >= a.Nx) || (jlo <= 0)))
-        prk_band_fast<W, BLOCK, true>(a.go, a.ge, s_ft, sD, r, jhi, w, M, D);      // some flank has run out at its far end
+      // LEAN (see prk_band_fast): no lane of the wave can contribute more than its cap to the next vote or set a record
+      const bool maskhi_ok = a.pack_ok > 1 && r >= W && __all((n >= a.Nx) || (jlo <= 0));
+      const bool lean = lean_now;                      // decided at the end of the previous column (same inputs), see below
+      if (all_in)
+      {
+        if (lean) prk_band_fast<W, BLOCK, false, true>(a.go, a.ge, s_ft, sD, r, 0, w, M, D);
+        else prk_band<W, false, BLOCK>(a.go, a.ge, s_tab, s_ft, sD, r, w, jlo, jhi, M, D);
+      }
+      else if (maskhi_ok)
+      {
+        if (lean) prk_band_fast<W, BLOCK, true, true>(a.go, a.ge, s_ft, sD, r, jhi, w, M, D);
+        else prk_band_fast<W, BLOCK, true>(a.go, a.ge, s_ft, sD, r, jhi, w, M, D);      // some flank has run out at its far end
+      }
       else prk_band<W, true, BLOCK>(a.go, a.ge, s_tab, s_ft, sD, r, w, jlo, jhi, M, D);
+      prevBest = D.bestF;
       if (D.bestF > high) { high = D.bestF; pos = r + D.jbest - W; }   // ram_extend.c:1140-1150
       if (new_max) { thigh = high; tpos = pos; }                        // :1203-1207
+      // Will column r+1 be a LEAN one for this wave?  (prk_band_fast: no lane can contribute more than its cap to the vote of
+      // row r+2 or set a record in row r+1, and the wave takes one of the in-bounds fast variants.)  Everything the test reads
+      // is final now: prevBest = best cell of row r, high after row r, the bounds of row r+1.
+      {
+        const int jlo1 = jlo - 1, jhi1 = jhi - 1;
+        const bool all_in1 = a.pack_ok && __all((n >= a.Nx) || ((jlo1 <= 0) && (jhi1 >= B)));
+        const bool maskhi1 = a.pack_ok > 1 && r + 1 >= W && __all((n >= a.Nx) || (jlo1 <= 0));
+        const int capfloor = (high + a.cap) > 0 ? (high + a.cap) : 0;
+        lean_now = a.lean_p >= 0 && (all_in1 || maskhi1) &&
+                   __all((n >= a.Nx) || ((prevBest + 2 * a.lean_p <= capfloor) && (prevBest + a.lean_p <= high)));
+      }
       if (n < a.Nx)
       {
         const int capv = high + a.cap;
@@ -655,7 +732,7 @@ __global__ __launch_bounds__(BLOCK, 2) void ramx_persistent_kernel(const PArgs a
       long long t = 0;
 #pragma unroll
       for (int wv = 0; wv < WPB; wv++) t += s_red[wv][threadIdx.x];
-      PShard *sh = a.vote + (size_t)((r + 1) & 3) * NSHARD + shard;
+      PShard *sh = a.vote + (size_t)((r + 1) & (PRK_NSETS - 1)) * NSHARD + shard;
       __hip_atomic_fetch_add(&sh->word[threadIdx.x], (unsigned long long)t + PRK_BIAS + PRK_TICKET, __ATOMIC_RELAXED,
                              __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -713,6 +790,7 @@ struct FArgs
   int Np, L, go, ge, cap, minimp, when_to_stop;
   int tab[RAMX_NCLASS][4];
   int pack_ok;
+  int lean_p;                   // P of the LEAN test (see PArgs)
   unsigned long long *dbg;      // -DRAMX_PRK_TIMING builds only
 };
 
@@ -753,6 +831,7 @@ __global__ __launch_bounds__(BLOCK, 2) void ramx_family_kernel(const FArgs a)
 #pragma unroll
   for (int j = 0; j < B; j++) M[j] = 0;
   int high = 0, pos = 0, thigh = 0, tpos = 0;
+  int prevBest = 0x3fffffff;             // best cell of the previous row (LEAN test)
   const int2 bd = a.bounds[n];
   long long max_ext = 0;
   int max_row = -1, rows_done = 0, ovf = 0, stopped = 0;
@@ -829,10 +908,20 @@ __global__ __launch_bounds__(BLOCK, 2) void ramx_family_kernel(const FArgs a)
         // padding lanes (no flank: their base stream is all N, their vote is masked) must not force the whole wave onto
         // the masked path -- with N not a multiple of 64 that one slow wave would gate every column
         const bool all_in = a.pack_ok && __all((!active) || ((jlo <= 0) && (jhi >= B)));
-        if (all_in) prk_band<W, false, BLOCK>(a.go, a.ge, s_tab, s_ft, sD, r, w, jlo, jhi, M, D);
+        const int capfloor = (high + a.cap) > 0 ? (high + a.cap) : 0;
+        const bool lean = a.lean_p >= 0 && __all((!active) || ((prevBest + 2 * a.lean_p <= capfloor) && (prevBest + a.lean_p <= high)));
+        if (all_in)
+        {
+          if (lean) prk_band_fast<W, BLOCK, false, true>(a.go, a.ge, s_ft, sD, r, 0, w, M, D);
+          else prk_band<W, false, BLOCK>(a.go, a.ge, s_tab, s_ft, sD, r, w, jlo, jhi, M, D);
+        }
         else if (a.pack_ok > 1 && r >= W && __all(!active || (jlo <= 0)))
-          prk_band_fast<W, BLOCK, true>(a.go, a.ge, s_ft, sD, r, jhi, w, M, D);
+        {
+          if (lean) prk_band_fast<W, BLOCK, true, true>(a.go, a.ge, s_ft, sD, r, jhi, w, M, D);
+          else prk_band_fast<W, BLOCK, true>(a.go, a.ge, s_ft, sD, r, jhi, w, M, D);
+        }
         else prk_band<W, true, BLOCK>(a.go, a.ge, s_tab, s_ft, sD, r, w, jlo, jhi, M, D);
+        prevBest = D.bestF;
         if (D.bestF > high) { high = D.bestF; pos = r + D.jbest - W; }
         if (new_max) { thigh = high; tpos = pos; }
       }

@@ -153,3 +153,53 @@ def test_fast_band_bounds_and_fallback(W, monkeypatch):
         assert b[2].persistent == (1 if k < 900 else 0)
         # scaling every score scales nothing else: same consensus and lengths as the unscaled run
         assert np.array_equal(a[1], ref[1]) and np.array_equal(a[0].left_len, ref[0].left_len)
+
+
+def _two_copy_family(n, L, W, gap, seed, short_frac=0.0):
+    """Flanks = 300 aligned columns, `gap` random columns, then a SECOND shared copy (300 columns, 8 % substitutions, same
+    offset in every flank): behind the first copy every flank sinks to its cap (the lean band's territory), the second copy
+    makes the row scores climb again -- the band must leave the lean variant exactly when a lane could matter again."""
+    fs = synth_family(n, L, W, K=300, seed=seed, core_len=12)
+    win = len(fs.sequence) // n
+    seq = fs.sequence.reshape(n, win).copy()
+    rng = np.random.default_rng(seed + 1)
+    anc2 = rng.integers(0, 4, size=300, dtype=np.int8)
+    s0 = 12 + 300 + gap
+    block = np.broadcast_to(anc2, (n, 300)).copy()
+    sub = rng.random((n, 300)) < 0.08
+    block[sub] = (block[sub] + rng.integers(1, 4, size=int(sub.sum()))) & 3
+    seq[:, s0:s0 + 300] = block
+    fs.sequence = np.ascontiguousarray(seq.reshape(-1))
+    if short_frac > 0:            # some flanks end early: their waves run the far-end-masked variants
+        short = np.nonzero(rng.random(n) < short_frac)[0]
+        fs.cores.upper[short] = fs.cores.right_pos[short] + rng.integers(200, 900, size=len(short))
+    return fs
+
+
+@pytest.mark.parametrize("W,matrix,gap,short_frac", [(40, "14p43g", 400, 0.0), (14, "20p43g", 250, 0.0), (20, "25p43g", 300, 0.05),
+                                                       (40, "repeatscout", 350, 0.03)])
+def test_lean_band_switches_on_and_off_exactly(W, matrix, gap, short_frac, monkeypatch):
+    """The LEAN band (prk_band_fast<.., LEAN>: no candidate rows, no best-cell index, taken while no lane of a wave can
+    contribute more than its cap or set a record) across a run that leaves the alignment, sits at the cap for hundreds of
+    columns and then meets a second shared copy: consensus, stop row, lengths and scores equal the oracle's; the final DP rows
+    equal a run with RAMX_NO_LEAN=1 cell by cell.  All three routes of the autouse fixture (the cell-parallel one has no lean
+    variant and serves as a second reference)."""
+    L = 300 + gap + 300 + 150
+    fs = _two_copy_family(700, L, W, gap, seed=4100 + W, short_frac=short_frac)
+    p = po.Params.named(matrix, bandwidth=W, L=L, when_to_stop=L)
+    a = run_both_directions(oracle_extend, fs.cores, fs.sequence, p)
+    b = run_both_directions(gpu_extend, fs.cores, fs.sequence, p)
+    assert_same_result(a[0], a[1], a[2:], b[0], b[1], b[2:], f"W={W} {matrix}")
+    assert (a[2].rows_executed, a[2].ret) == (b[2].rows_executed, b[2].ret) and a[2].rows_executed == L
+    # the second copy really is found again (the consensus behind the gap is the second ancestor, the best row lies in it)
+    assert a[2].ret > 300 + gap
+    import os
+    if os.environ.get("RAMX_NO_CP_DEVICE"):
+        lean = _run_device(fs, p, 1, monkeypatch, True)
+        monkeypatch.setenv("RAMX_NO_LEAN", "1")
+        full = _run_device(fs, p, 1, monkeypatch, True)
+        monkeypatch.delenv("RAMX_NO_LEAN")
+        assert lean[0].persistent == 1 and lean[0].lanes_per_flank == 1
+        assert np.array_equal(lean[1], full[1]) and np.array_equal(lean[2], full[2]) and np.array_equal(lean[3], full[3])
+        for (ca, ha, pa), (cb, hb, pb) in zip(lean[4], full[4]):
+            assert np.array_equal(ca, cb) and (ha, pa) == (hb, pb)
