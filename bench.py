@@ -289,7 +289,7 @@ def main():
             doc = json.load(open(pmc))
             ent = doc.get("persistent" if persistent else "column", {})
             cfg = doc.get("config", {"flanks": 100000, "bandwidth": 40})
-            if cfg.get("flanks") == N and cfg.get("bandwidth") == W and lanes == 1:
+            if cfg.get("flanks") == N and cfg.get("bandwidth") == W and lanes == 1 and cfg.get("L", L) == L:
                 per_col = ent.get("hbm_bytes_per_column")
                 fit = doc.get("persistent_fit")
                 if persistent and fit:
@@ -322,7 +322,7 @@ def main():
         ginst = insts_per_col / (us_col * 1e-6) / 1e9           # wave64 VALU instructions per second, whole chip
         mix = None
         try:
-            mix = json.load(open(os.path.join(ROOT, "profiles", "r02_valu_mix_persistent.json")))
+            mix = json.load(open(os.path.join(ROOT, "profiles", "r03_valu_mix_persistent.json")))
         except Exception:
             pass
         valu = {"insts_per_column": insts_per_col, "G_wave_inst_per_sec": ginst, "pmc_source": pmc_source,

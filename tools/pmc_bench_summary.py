@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""profiles/pmc_summary.json (what bench.py's roofline block reads) from the PMC passes of the WHOLE bench launch:
+profiles/TAG_pmc_bench.json (tools/pmc_summary2.py format) -> the `persistent` entry, per-column figures = per-launch / COLS.
+Since round 3 the kernel's work per column depends on the phase (full band while the flanks align, LEAN band behind the end
+of the alignment), so the counters are taken over the bench's own 10,000-column launch, not over a 256-column one.
+usage: pmc_bench_summary.py TAG COLS FLANKS BANDWIDTH"""
+import json, os, sys
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag, cols, flanks, W = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+doc = json.load(open(os.path.join(root, "profiles", f"{tag}_pmc_bench.json")))
+ent = None
+for k, v in doc.items():
+    if "ramx_persistent_kernel" in k:
+        ent = v
+assert ent is not None, list(doc)
+a = ent["avg_per_dispatch"]
+out = {"tag": tag, "persistent": {"dispatches": ent["dispatches"], "avg_per_dispatch": a, "columns_per_launch": cols}}
+if "FETCH_SIZE" in a and "WRITE_SIZE" in a:
+    # gfx950 correction of MI355X_MICROARCH.md (HBM section): FETCH_SIZE (KiB) x 2 for wide coalesced loads, WRITE_SIZE (KiB) exact
+    p = out["persistent"]
+    p["fetch_bytes_corrected"] = a["FETCH_SIZE"] * 1024 * 2
+    p["write_bytes"] = a["WRITE_SIZE"] * 1024
+    p["hbm_bytes_per_launch"] = p["fetch_bytes_corrected"] + p["write_bytes"]
+    p["hbm_bytes_per_column"] = p["hbm_bytes_per_launch"] / cols
+out["config"] = {"flanks": flanks, "bandwidth": W, "L": cols,
+                 "command": "python3 bench.py --steps 1 --warmup 0 --no-cpu --no-seam1   (one rocprofv3 --pmc pass per counter set)"}
+json.dump(out, open(os.path.join(root, "profiles", "pmc_summary.json"), "w"), indent=1)
+print(json.dumps({k: out["persistent"].get(k) for k in ("columns_per_launch", "hbm_bytes_per_launch", "hbm_bytes_per_column")}),
+      "SQ_INSTS_VALU per column:", a.get("SQ_INSTS_VALU", 0) / cols)

@@ -29,7 +29,7 @@ pmc() {  # name, command...
   python3 tools/pmc_summary2.py $O/pmc_$name > $O/pmc_$name.json; rm -rf $O/pmc_$name $O/pmc_$name.pass*.log
   echo "pmc $name done"
 }
-pmc bench python3 bench.py --steps 1 --warmup 0 --no-cpu --no-seam1 --L 256
+pmc bench python3 bench.py --steps 1 --warmup 0 --no-cpu --no-seam1
 pmc cp_n1000 python3 tools/cp_spec_timing.py 1000
 pmc cp_n12500 python3 tools/cp_spec_timing.py 12500
 ls $O
