@@ -282,6 +282,7 @@ def main():
     traffic = None
     valu = None
     insts_per_col = None
+    full_band_insts = None
     pmc_source = None
     pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
     if os.path.exists(pmc) and world == 1:
@@ -302,6 +303,7 @@ def main():
                 cols_prof = ent.get("columns_per_launch") or (ent["hbm_bytes_per_launch"] / ent["hbm_bytes_per_column"] if ent.get("hbm_bytes_per_column") else None)
                 if cnt.get("SQ_INSTS_VALU") and cols_prof:
                     insts_per_col = cnt["SQ_INSTS_VALU"] / (cols_prof if persistent else 1.0)
+                    full_band_insts = ent.get("full_band_insts_per_column") if persistent else None
                     pmc_source = "profiles/pmc_summary.json"
         except Exception:
             traffic = None
@@ -327,6 +329,10 @@ def main():
             pass
         valu = {"insts_per_column": insts_per_col, "G_wave_inst_per_sec": ginst, "pmc_source": pmc_source,
                 "peak_guide_2cycle": VALU_PEAK_GINST, "frac_guide_2cycle": ginst / VALU_PEAK_GINST}
+        if full_band_insts:
+            # the LEAN band skips work that provably cannot matter: what the same columns would cost with the full band everywhere
+            valu["full_band_insts_per_column"] = full_band_insts
+            valu["frac_if_every_column_ran_the_full_band"] = full_band_insts / (us_col * 1e-6) / 1e9 / VALU_PEAK_GINST
         if mix and persistent and lanes == 1:
             # instruction-mix-weighted issue cost of the band (static mix of the hot blocks x measured ticks per opcode class)
             tpi = mix["hot_blocks_ticks_per_valu"]

@@ -177,9 +177,24 @@ static int cp_launch_dev(hipStream_t st, int threads, int blocks, const CPArgs &
   else
   {
     if (threads > CpCfg<W, K>::MAXT_DEV) return RAMX_ERR_ARG;
-    int per_cu = 0, dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return RAMX_ERR_HIP;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ramx_cp_kernel<W, K, true>, threads, 0) != hipSuccess) return RAMX_ERR_HIP;
+    // occupancy of this instantiation at this workgroup size and the CU count: asked once per process and device
+    // (the answers do not change; the query costs tens of microseconds per launch)
+    static int c_dev = -1, c_cus = 0, c_per_cu[1024 / 64 + 1];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return RAMX_ERR_HIP;
+    if (dev != c_dev)
+    {
+      if (hipDeviceGetAttribute(&c_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return RAMX_ERR_HIP;
+      for (int i = 0; i <= 1024 / 64; i++) c_per_cu[i] = -1;
+      c_dev = dev;
+    }
+    if (c_per_cu[threads / 64] < 0)
+    {
+      int q = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, ramx_cp_kernel<W, K, true>, threads, 0) != hipSuccess) return RAMX_ERR_HIP;
+      c_per_cu[threads / 64] = q;
+    }
+    const int per_cu = c_per_cu[threads / 64], cus = c_cus;
     if (per_cu < 1 || blocks > cus) return RAMX_ERR_UNSUPPORTED;      // one workgroup per CU by design
     // plain launch (see prk_launch in ramx_device.hip: the co-residency check is done here, the kernel's barrier is
     // bounded, and a cooperative launch makes rocprofv3-profiled processes crash at exit); RAMX_COOP_LAUNCH=1 restores it
