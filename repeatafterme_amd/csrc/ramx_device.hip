@@ -638,30 +638,48 @@ static int prk_plan(int tiles, int *block, int *blocks)
     *block = 256; *blocks = (tiles + 3) / 4;
     return RAMX_OK;
   }
-  if ((rc = prk_capacity_blocks<W, 512>(&cap)) != RAMX_OK) return rc;
-  if ((tiles + 7) / 8 <= cap) { *block = 512; *blocks = (tiles + 7) / 8; }
+  if constexpr (W <= 40)     // wider bands have no two-waves-per-SIMD shape: the row needs more than 256 registers
+  {
+    if ((rc = prk_capacity_blocks<W, 512>(&cap)) != RAMX_OK) return rc;
+    if ((tiles + 7) / 8 <= cap) { *block = 512; *blocks = (tiles + 7) / 8; }
+  }
   return RAMX_OK;
 }
 
 // which band widths have a register-resident instantiation
-static bool prk_has_width(int W) { return W == 14 || W == 20 || W == 40; }
+static bool prk_has_width(int W) { return W == 14 || W == 20 || W == 40 || W == 80; }
+// ... and which have a one-workgroup-per-family instantiation (ramx_family_kernel: two waves per SIMD, 256 registers)
+static bool fam_has_width(int W) { return W == 14 || W == 20 || W == 40; }
+
+// this rank's own answer to "can the lane-per-flank persistent kernel run this direction", and its launch shape
+static int prk_local_can(ramx_dev *d, const KArgs &a, int L, bool multi, bool *can_out, int *block, int *blocks)
+{
+  const int W = a.W;
+  const int tiles = d->Np / 64;
+  int rc;
+  *block = 0; *blocks = 0;
+  bool can = !(getenv("RAMX_NO_PERSISTENT") != NULL || d->force_chain || a.go > 0 || a.ge > 0 || a.go + a.ge < -32768 ||
+               !prk_has_width(W) || L <= 0);
+  if (multi && (!d->peer_ready || d->nranks < 2 || L >= 65536 || getenv("RAMX_NO_PEER") != NULL)) can = false;
+  if (can)
+  {
+    rc = (W == 14) ? prk_plan<14>(tiles, block, blocks) : (W == 20) ? prk_plan<20>(tiles, block, blocks) :
+         (W == 40) ? prk_plan<40>(tiles, block, blocks) : prk_plan<80>(tiles, block, blocks);
+    if (rc != RAMX_OK) return rc;
+    if (*block == 0) can = false;          // not co-resident: keep the streaming kernel
+  }
+  *can_out = can;
+  return RAMX_OK;
+}
 
 static int prk_run(ramx_dev *d, const KArgs &a, int L, bool *used)
 {
   *used = false;
   const int W = a.W;
   const bool multi = (d->comm != NULL && d->nranks > 1) || d->cb != NULL;
-  const int tiles = d->Np / 64;
   int block = 0, blocks = 0, rc;
-  bool can = !(getenv("RAMX_NO_PERSISTENT") != NULL || d->force_chain || a.go > 0 || a.ge > 0 || a.go + a.ge < -32768 ||
-               !prk_has_width(W) || L <= 0);
-  if (multi && (!d->peer_ready || d->nranks < 2 || L >= 65536 || getenv("RAMX_NO_PEER") != NULL)) can = false;
-  if (can)
-  {
-    rc = (W == 14) ? prk_plan<14>(tiles, &block, &blocks) : (W == 20) ? prk_plan<20>(tiles, &block, &blocks) : prk_plan<40>(tiles, &block, &blocks);
-    if (rc != RAMX_OK) return rc;
-    if (block == 0) can = false;          // not co-resident: keep the streaming kernel
-  }
+  bool can = false;
+  if ((rc = prk_local_can(d, a, L, multi, &can, &block, &blocks)) != RAMX_OK) return rc;
   if (multi)
   {
     // every rank must take the same path: agree (max over ranks of "cannot")
@@ -728,7 +746,8 @@ static int prk_run(ramx_dev *d, const KArgs &a, int L, bool *used)
   HIPCHK(hipMemset(pa.dbg, 0, nw * 8 * sizeof(unsigned long long)));
 #endif
   if (block == 256)
-    rc = (W == 14) ? prk_launch<14, 256>(d, pa, blocks) : (W == 20) ? prk_launch<20, 256>(d, pa, blocks) : prk_launch<40, 256>(d, pa, blocks);
+    rc = (W == 14) ? prk_launch<14, 256>(d, pa, blocks) : (W == 20) ? prk_launch<20, 256>(d, pa, blocks) :
+         (W == 40) ? prk_launch<40, 256>(d, pa, blocks) : prk_launch<80, 256>(d, pa, blocks);
   else
     rc = (W == 14) ? prk_launch<14, 512>(d, pa, blocks) : (W == 20) ? prk_launch<20, 512>(d, pa, blocks) : prk_launch<40, 512>(d, pa, blocks);
 #ifdef RAMX_PRK_TIMING
@@ -807,7 +826,7 @@ static int run_families_pass(ramx_dev *d, const ramx_flank *flanks, int32_t n_pa
   const int W = p->bandwidth, L = p->L;
   if (W < 1 || L < 0) { ramx_set_error("ramx_dev_run_families: bad bandwidth / L"); return RAMX_ERR_ARG; }
   // register-resident family kernel where it applies, the streaming family kernel for everything else
-  const bool resident = prk_has_width(W) && p->gapopen <= 0 && p->gapextn <= 0 && p->gapopen + p->gapextn >= -32768 &&
+  const bool resident = fam_has_width(W) && p->gapopen <= 0 && p->gapextn <= 0 && p->gapopen + p->gapextn >= -32768 &&
                         !d->force_chain && getenv("RAMX_NO_PERSISTENT") == NULL;
   int maxn = 0;
   for (int f = 0; f < n_families; f++)

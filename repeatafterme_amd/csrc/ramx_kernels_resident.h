@@ -437,8 +437,10 @@ __device__ __forceinline__ void prk_band(const int go, const int ge, const int *
   }
 }
 
+// W = 80 (161 cells per lane): one wave per SIMD only, so that the row has the whole register file of the lane (the
+// accumulation registers take what the 256 architectural ones cannot hold)
 template <int W, int BLOCK>
-__global__ __launch_bounds__(BLOCK, 2) void ramx_persistent_kernel(const PArgs a)
+__global__ __launch_bounds__(BLOCK, (W > 40 ? 1 : 2)) void ramx_persistent_kernel(const PArgs a)
 {
   constexpr int B = 2 * W + 1, Q = W + 1, NW = (B + 8) / 8 + 2, WPB = BLOCK / 64, RS = 2 * BLOCK;   // RS: shorts per cell-pair row of sD
   // one object, tables first: their LDS addresses must fit the 16-bit offset field of the ds_read that uses them

@@ -135,3 +135,23 @@ def test_wrapper_configuration_long_L(n, route):
     assert np.array_equal(m1, m2), route
     assert np.array_equal(c1.left_len, c2.left_len) and np.array_equal(c1.right_len, c2.right_len), route
     assert np.array_equal(c1.score, c2.score), route
+
+
+def test_w80_above_the_cell_parallel_capacity_stays_register_resident():
+    """W = 80 (161 cells per flank; the wrapper's widest band, util/extend-stk.pl:365) with more flanks than the cell-parallel
+    kernel holds at 4 lanes per flank (32,768): the lane-per-flank kernel with ONE wave per SIMD keeps the row on chip (half
+    of it in accumulation registers), up to 65,536 flanks.  44,000 flanks, 40 columns (rows < W: general band; a few flanks
+    end early: masked waves) against the oracle."""
+    n, Lx = 44_000, 40
+    fs = synth_family(n, Lx, 80, K=400, seed=808, core_len=170)
+    rng = np.random.default_rng(5)
+    short = np.nonzero(rng.random(n) < 0.01)[0]
+    fs.cores.upper[short] = fs.cores.right_pos[short] + rng.integers(0, 30, size=len(short))
+    p = po.Params.named("20p43g", bandwidth=80, L=Lx, when_to_stop=Lx)
+    c1, c2 = fs.cores.copy(), fs.cores.copy()
+    m1, m2 = new_master(Lx), new_master(Lx)
+    a = po.oracle_extend(1, c1, fs.sequence, m1, p)
+    b = gpu_extend(1, c2, fs.sequence, m2, p)
+    assert b.persistent == 1 and b.lanes_per_flank == 1
+    assert (a.ret, a.rows_executed) == (b.ret, b.rows_executed)
+    assert np.array_equal(m1, m2) and np.array_equal(c1.right_len, c2.right_len) and np.array_equal(c1.score, c2.score)

@@ -1,6 +1,6 @@
 """The persistent register-resident kernel (one launch per direction, rows on chip, vote fused with a
-device-wide barrier) against the streaming per-column kernel and the oracle.  Band widths 14, 20 and 40 have a
-persistent instantiation; everything else, positive gap penalties, flank sets too large to be co-resident and
+device-wide barrier) against the streaming per-column kernel and the oracle.  Band widths 14, 20, 40 and 80 (one wave per
+SIMD only) have a persistent instantiation; everything else, positive gap penalties, flank sets too large to be co-resident and
 multi-rank runs use the streaming kernel."""
 import numpy as np
 import pytest
@@ -46,7 +46,7 @@ def _run_device(fs, p, direction, monkeypatch, persistent):
     return info, cons, th, tp, state
 
 
-@pytest.mark.parametrize("W", [14, 20, 40])
+@pytest.mark.parametrize("W", [14, 20, 40, 80])
 def test_persistent_equals_streaming_and_oracle(W, monkeypatch):
     for seed in (300, 301, 302, 303):
         fs = synth_adversarial(seed, lowercase=(seed % 2 == 0))
@@ -129,7 +129,7 @@ def _scaled(p, k):
     return q
 
 
-@pytest.mark.parametrize("W", [14, 40])
+@pytest.mark.parametrize("W", [14, 40, 80])
 def test_fast_band_bounds_and_fallback(W, monkeypatch):
     """The in-bounds fast band packs (score << 4 | cell) keys and reads int8 scores; scoring systems outside those
     bounds must take the general band for every wave (host check), and the switch RAMX_NO_FASTPACK forces it."""
@@ -177,7 +177,7 @@ def _two_copy_family(n, L, W, gap, seed, short_frac=0.0):
 
 
 @pytest.mark.parametrize("W,matrix,gap,short_frac", [(40, "14p43g", 400, 0.0), (14, "20p43g", 250, 0.0), (20, "25p43g", 300, 0.05),
-                                                       (40, "repeatscout", 350, 0.03)])
+                                                       (40, "repeatscout", 350, 0.03), (80, "20p43g", 300, 0.03)])
 def test_lean_band_switches_on_and_off_exactly(W, matrix, gap, short_frac, monkeypatch):
     """The LEAN band (prk_band_fast<.., LEAN>: no candidate rows, no best-cell index, taken while no lane of a wave can
     contribute more than its cap or set a record) across a run that leaves the alignment, sits at the cap for hundreds of

@@ -8,7 +8,7 @@ from repeatafterme_amd.synth import synth_family
 
 L = 1000
 sizes = [int(x) for x in sys.argv[1:]] or [1000, 2000, 4000, 8000, 16000, 32000, 65000]
-for W in (40, 80):
+for W in [int(x) for x in os.environ.get("TIMING_W", "40,80").split(",")]:
     for n in sizes:
         fs = synth_family(n, L, W, K=600, seed=5, core_len=2 * W + 4)
         p = named_params("14p43g" if W != 80 else "20p43g", bandwidth=W, L=L)

@@ -24,6 +24,12 @@ if "FETCH_SIZE" in a and "WRITE_SIZE" in a:
     p["hbm_bytes_per_column"] = p["hbm_bytes_per_launch"] / cols
 out["config"] = {"flanks": flanks, "bandwidth": W, "L": cols,
                  "command": "python3 bench.py --steps 1 --warmup 0 --no-cpu --no-seam1   (one rocprofv3 --pmc pass per counter set)"}
-json.dump(out, open(os.path.join(root, "profiles", "pmc_summary.json"), "w"), indent=1)
+dst = os.path.join(root, "profiles", "pmc_summary.json")
+if os.path.exists(dst):   # the 256-column full-band count is measured separately (tools/pmc.sh); keep it across refreshes
+    old = json.load(open(dst)).get("persistent", {})
+    for k in ("full_band_insts_per_column", "full_band_source"):
+        if k in old:
+            out["persistent"][k] = old[k]
+json.dump(out, open(dst, "w"), indent=1)
 print(json.dumps({k: out["persistent"].get(k) for k in ("columns_per_launch", "hbm_bytes_per_launch", "hbm_bytes_per_column")}),
       "SQ_INSTS_VALU per column:", a.get("SQ_INSTS_VALU", 0) / cols)
