@@ -738,6 +738,9 @@ static int prk_run(ramx_dev *d, const KArgs &a, int L, bool *used)
   pa.pack_ok = getenv("RAMX_NO_FASTPACK") ? 0 : fast_pack_ok(pa.tab, a.go, a.ge, L, W);
   if (pa.pack_ok && getenv("RAMX_NO_MASKHI") == NULL) pa.pack_ok = 2;      // 2: the far-end-masked fast band may be used too
   pa.lean_p = lean_p_of(pa.tab, a.go, a.ge);
+  // a leader costs its wave ~150 instructions in prk_leader_rows, the full band 640 more than LEAN; RAMX_LEADER_MAX=0 switches
+  // the leader path off (A/B and tests), larger values exercise it on waves with many leaders
+  { const char *lm = getenv("RAMX_LEADER_MAX"); pa.leader_max = lm ? atoi(lm) : 3; if (pa.leader_max < 0) pa.leader_max = 0; if (pa.leader_max > 64) pa.leader_max = 64; }
   HIPCHK(hipMemsetAsync(d->d_vote, 0, PRK_NSETS * NSHARD * sizeof(PShard), d->stream));
   HIPCHK(hipMemsetAsync(d->d_err, 0, 64, d->stream));
 #ifdef RAMX_PRK_TIMING
@@ -781,6 +784,32 @@ static int prk_run(ramx_dev *d, const KArgs &a, int L, bool *used)
       fprintf(stderr, " w%d %.0f", wv, sw / (blocks > 1 ? blocks - 1 : 1));
     }
     fprintf(stderr, "\n");
+    {
+      // second half of the run: waves that were kept from the LEAN band, and by how many lanes
+      const double half = L - L / 2;
+      size_t never = 0, always = 0, wg_any = 0;
+      double lanes = 0, cols = 0;
+      int hist[6] = { 0, 0, 0, 0, 0, 0 };       // waves by average number of such lanes in their non-lean columns: <=1, <=2, <=4, <=8, <=16, more
+      for (int b = 0; b < blocks; b++)
+      {
+        bool any = false;
+        for (int wv = 0; wv < wpb; wv++)
+        {
+          const size_t i = (size_t)b * wpb + wv;
+          const double c = (double)h[i * 8 + 6], l = (double)h[i * 8 + 7];
+          if (c == 0) { never++; continue; }
+          any = any || c > 0.5 * half;
+          if (c > 0.9 * half) always++;
+          lanes += l; cols += c;
+          const double avg = l / c;
+          hist[avg <= 1 ? 0 : avg <= 2 ? 1 : avg <= 4 ? 2 : avg <= 8 ? 3 : avg <= 16 ? 4 : 5]++;
+        }
+        if (any) wg_any++;
+      }
+      fprintf(stderr, "PRK_LEANSTAT second half (%.0f columns): %zu of %zu waves always LEAN, %zu non-LEAN in > 90 %% of the columns; workgroups with a wave "
+              "non-LEAN in > 50 %%: %zu of %d; lanes per non-LEAN wave-column %.2f; waves by that average <=1: %d <=2: %d <=4: %d <=8: %d <=16: %d more: %d\n",
+              half, never, nw, always, wg_any, blocks, cols > 0 ? lanes / cols : 0.0, hist[0], hist[1], hist[2], hist[3], hist[4], hist[5]);
+    }
     free(h);
     (void)hipFree(pa.dbg);
   }

@@ -216,6 +216,20 @@ __device__ __forceinline__ unsigned wave_sum_u32_dpp(unsigned v)
   v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
   return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
+// maximum over the wave (same DPP steps), returned to every lane through the scalar unit
+__device__ __forceinline__ int wave_max_i32_dpp(int v)
+{
+  const int lowest = -2147483647 - 1;
+#define RAMX_MAX_STEP(ctrl, rows) do { const int o_ = __builtin_amdgcn_update_dpp(lowest, v, ctrl, rows, 0xf, false); v = v > o_ ? v : o_; } while (0)
+  RAMX_MAX_STEP(0xB1, 0xf);     // quad_perm:[1,0,3,2]
+  RAMX_MAX_STEP(0x4E, 0xf);     // quad_perm:[2,3,0,1]
+  RAMX_MAX_STEP(0x124, 0xf);    // row_ror:4
+  RAMX_MAX_STEP(0x128, 0xf);    // row_ror:8  -> row maxima everywhere
+  RAMX_MAX_STEP(0x142, 0xa);    // row_bcast:15 into rows 1 and 3
+  RAMX_MAX_STEP(0x143, 0xc);    // row_bcast:31 into rows 2 and 3
+#undef RAMX_MAX_STEP
+  return __builtin_amdgcn_readlane(v, 63);
+}
 __device__ __forceinline__ long long wave_sum_nonneg31(int v)
 {
   const unsigned lo = wave_sum_u32_dpp((unsigned)v & 0xffffu), hi = wave_sum_u32_dpp((unsigned)v >> 16);

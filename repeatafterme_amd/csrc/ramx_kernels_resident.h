@@ -99,6 +99,7 @@ struct PArgs
   int tab[RAMX_NCLASS][4];
   int pack_ok;                  // every reachable score fits 27 bits: the fast path may pack (score, cell) keys
   int lean_p;                   // P = max(0, largest matrix entry) of the LEAN test (prk_band_fast); -1: never LEAN
+  int leader_max;               // a wave with at most this many lanes that fail the LEAN test runs LEAN + prk_leader_rows (0: off)
   unsigned long long *dbg;      // -DRAMX_PRK_TIMING builds only: [block][8] phase sums in 10 ns ticks
 };
 
@@ -284,8 +285,12 @@ __device__ __forceinline__ void prk_band_fast(const int go_, const int ge_, cons
     unsigned off;
     if constexpr ((jn & 1) == 0) off = nib_lo_x16<byte>(Alo);
     else off = nib_hi_x16<byte>(A, mask_f0);
+#ifdef PRK_PROBE_NO_TABLE
+    return make_int2((int)off, (int)off >> 3);      // timing probe: no LDS lookup (wrong results)
+#else
     if constexpr (LEAN) return make_int2(0, *reinterpret_cast<const int *>(tb + off + 4));    // the winner's score only
     else return *reinterpret_cast<const int2 *>(tb + off);
+#endif
   };
   static_for([&](auto kc) __attribute__((always_inline))
   {
@@ -293,8 +298,15 @@ __device__ __forceinline__ void prk_band_fast(const int go_, const int ge_, cons
     if constexpr (k <= B) rowQ[k] = fetch_row(std::integral_constant<int, (k <= B ? k : 0)>{});
     else rowQ[k] = make_int2(0, 0);
   }, std::make_integer_sequence<int, PD>{});
-  dCurW = myDW[0];                                   // pair 0: cell 1 is step 0's deletion predecessor
-  if constexpr (B > 2) dNxtW = myDW[BLOCK];          // pair 1
+#ifdef PRK_PROBE_NO_DROW
+#define PRK_DLOAD(x) (r + (x))                       /* timing probe: the d-row stays out of LDS (wrong results) */
+#define PRK_DSTORE(p, v) asm volatile("" :: "v"((int)(v)))
+#else
+#define PRK_DLOAD(x) myDW[x]
+#define PRK_DSTORE(p, v) (p) = (v)
+#endif
+  dCurW = PRK_DLOAD(0);                              // pair 0: cell 1 is step 0's deletion predecessor
+  if constexpr (B > 2) dNxtW = PRK_DLOAD(BLOCK);     // pair 1
   auto step = [&](auto jc) __attribute__((always_inline))
   {
     constexpr int j = decltype(jc)::value;
@@ -313,7 +325,7 @@ __device__ __forceinline__ void prk_band_fast(const int go_, const int ge_, cons
     if constexpr ((j & 1) != 0 && j + 1 < B)
     {
       dCurW = dNxtW;
-      if constexpr (((j + 1) >> 1) + 1 <= (B - 1) / 2) dNxtW = myDW[(((j + 1) >> 1) + 1) * BLOCK];
+      if constexpr (((j + 1) >> 1) + 1 <= (B - 1) / 2) dNxtW = PRK_DLOAD((((j + 1) >> 1) + 1) * BLOCK);
     }
     const bool inb = MASKHI ? (j <= jhi) : true;     // this step's cell of row r and candidate cell j-1 of row r+1
     // candidates' cell j-1 of row r+1: substitution from m_{j-1} of row r (the base of that cell is this step's)
@@ -344,8 +356,8 @@ __device__ __forceinline__ void prk_band_fast(const int go_, const int ge_, cons
       const int e = MASKHI ? (inb ? er : SENT + ge) : er;            // max(SENT + go, SENT) + ge with go <= 0
       M[j] = m;
       if constexpr ((j & 1) == 0 && j + 1 < B) dLo = e - m;
-      else if constexpr ((j & 1) != 0) myDW[(j >> 1) * BLOCK] = pack_halves(dLo, e - m);
-      else myD[(j >> 1) * (2 * BLOCK)] = (short)(e - m);           // cell 2W: the low half of the last pair
+      else if constexpr ((j & 1) != 0) PRK_DSTORE(myDW[(j >> 1) * BLOCK], pack_halves(dLo, e - m));
+      else PRK_DSTORE(myD[(j >> 1) * (2 * BLOCK)], (short)(e - m));           // cell 2W: the low half of the last pair
       // best cell: packed (value, cell) keys -- LEAN: the value alone (kg[0] is then a plain running maximum of m)
       const int kr = LEAN ? mr : (int)(((unsigned)mr << 4) | (unsigned)(15 - (j & 15)));
       const int key = MASKHI ? (inb ? kr : -2147483647 - 1) : kr;
@@ -389,6 +401,68 @@ __device__ __forceinline__ void prk_band_fast(const int go_, const int ge_, cons
   }
   D.bestF = bestv;
   D.jbest = 16 * bg + 15 - (bkey & 15);
+}
+
+// Leaders.  Behind the end of the alignment nearly every flank sits at its cap, but a FEW keep climbing -- the consensus follows
+// whoever still contributes above the cap, so those flanks match it column after column (measured on the N = 100,000 bench
+// set: one flank of 100,000, profiles/r03_notes.md).  Their wave must not run the LEAN band for them, and the full band for
+// one lane costs the wave (and every workgroup waiting for its ticket) 640 extra instructions per column.  Instead the wave
+// runs LEAN -- which updates the leader's row like everybody's -- and then computes what LEAN skipped for that ONE flank with
+// all 64 lanes: the leader's lane puts its new row and its base words into LDS, lane i takes cells i, i + 64, .. (candidate
+// cell k of row r+1 = m_k + M[a][class of step k+1], deletion terms e_j = m_j + d_j straight from the d-row), five wave
+// maxima and the lowest cell holding the row's best.  In-bounds waves only (the in-bounds fast variant's formulation).
+template <int W, int BLOCK>
+__device__ __forceinline__ void prk_leader_rows(const FastTabs &ft, const short *sD, int *scr /* [B + NW] of this wave */, const int r, const int leader,
+                                                const unsigned (&w)[(2 * W + 1 + 8) / 8 + 2], const int (&M)[2 * W + 1], LaneDP &D)
+{
+  constexpr int B = 2 * W + 1, NW = (B + 8) / 8 + 2;
+  constexpr int NH = (B + 63) / 64;                     // cells per lane
+  const int lane = threadIdx.x & 63;
+  if (lane == leader)
+  {
+#pragma unroll
+    for (int j = 0; j < B; j++) scr[j] = M[j];
+#pragma unroll
+    for (int k = 0; k < NW; k++) scr[B + k] = (int)w[k];
+  }
+  __builtin_amdgcn_wave_barrier();          // LDS operations of a wave execute in order; this only pins the compiler's order
+  const int ph = (r + 8) & 7;
+  const int thr = (threadIdx.x & ~63) + leader;        // the leader's thread: its column of the d-row
+  const int bf = __builtin_amdgcn_readlane(D.bestF, leader);
+  int ta[4] = { NEG, NEG, NEG, NEG }, me = NEG;
+  unsigned long long hit[NH];
+#pragma unroll
+  for (int h = 0; h < NH; h++)
+  {
+    const int k = lane + 64 * h;
+    const bool ok = k < B;
+    const int kk = ok ? k : 0;
+    const int m = scr[kk];
+    const int g = kk + 1 + ph;                         // nibble of step k+1 in the base words (prk_band_fast: alignbit by 4 * ph)
+    const unsigned cls = ((unsigned)scr[B + (g >> 3)] >> (4 * (g & 7))) & 15u;
+    const int sv = ft.row[cls][0];
+    if (ok)
+    {
+      ta[0] = imax(ta[0], add_sext_byte<0>(m, sv)); ta[1] = imax(ta[1], add_sext_byte<1>(m, sv));
+      ta[2] = imax(ta[2], add_sext_byte<2>(m, sv)); ta[3] = imax(ta[3], add_sext_byte<3>(m, sv));
+      if (k >= 1) me = imax(me, m + (int)sD[(kk >> 1) * (2 * BLOCK) + 2 * thr + (kk & 1)]);      // e_k, cells 1 .. B-1
+    }
+    hit[h] = __ballot(ok && m == bf);
+  }
+  const int mx = wave_max_i32_dpp(me);
+  int best[4];
+#pragma unroll
+  for (int c = 0; c < 4; c++) best[c] = imax(wave_max_i32_dpp(ta[c]), mx);
+  int jb = 0;                                          // lowest cell on ties (bnw_extend.c:1020-1024)
+#pragma unroll
+  for (int h = NH - 1; h >= 0; h--)
+    if (hit[h]) jb = 64 * h + __builtin_ctzll(hit[h]);
+  if (lane == leader)
+  {
+#pragma unroll
+    for (int c = 0; c < 4; c++) D.bestA[c] = best[c];
+    D.jbest = jb;
+  }
 }
 
 template <int W, bool OOB, int BLOCK, bool INIT = false>
@@ -451,6 +525,7 @@ __global__ __launch_bounds__(BLOCK, (W > 40 ? 1 : 2)) void ramx_persistent_kerne
     long long red[WPB][4];
     long long vote[4];
     int fail, pad[3];
+    int lead[WPB][B + NW + 1];                         // prk_leader_rows: a leader's row and base words, per wave
     short d[((B + 1) / 2) * RS];                       // d = e - m, [cell pair][thread][parity]
   };
   __shared__ __attribute__((aligned(16))) Smem sm;
@@ -471,7 +546,6 @@ __global__ __launch_bounds__(BLOCK, (W > 40 ? 1 : 2)) void ramx_persistent_kerne
   int M[B];
   int high, pos, thigh = 0, tpos = 0;
   int prevBest = 0x3fffffff;             // best cell of the previous row (LEAN test): unknown before the first band of this launch
-  bool lean_now = false;                 // this wave runs the LEAN band in the column that is about to start
   {
 #pragma unroll
     for (int q = 0; q < W; q++)
@@ -503,6 +577,7 @@ __global__ __launch_bounds__(BLOCK, (W > 40 ? 1 : 2)) void ramx_persistent_kerne
 
 #ifdef RAMX_PRK_TIMING
   unsigned long long tsum[6] = { 0, 0, 0, 0, 0, 0 }, tlast = wall_clock64();
+  unsigned long long lstat[2] = { 0, 0 };
 #endif
   for (int r = 0; r < a.L; r++)
   {
@@ -513,6 +588,10 @@ __global__ __launch_bounds__(BLOCK, (W > 40 ? 1 : 2)) void ramx_persistent_kerne
       const unsigned *bp = a.bases + (size_t)((r + 8) >> 3) * a.Np + n;
 #pragma unroll
       for (int k = 0; k < NW; k++) w[k] = bp[(size_t)k * a.Np];
+#ifdef PRK_PROBE_NO_BASES
+#pragma unroll
+      for (int k = 0; k < NW; k++) w[k] = 0x01230123u * (unsigned)(r + k);     // timing probe: no global loads (wrong results)
+#endif
     }
     // ---- vote of row r -----------------------------------------------------------------------
     if (wave == 0)
@@ -530,6 +609,9 @@ __global__ __launch_bounds__(BLOCK, (W > 40 ? 1 : 2)) void ramx_persistent_kerne
         const unsigned long long *src = &a.vote[(size_t)(r & (PRK_NSETS - 1)) * NSHARD + sidx].word[2 * half];
         unsigned spins = 0;
         bool done = my_shard_blocks <= 0 || (a.nranks > 1 && blockIdx.x != 0);   // multi-rank: only the exchanger needs the local total
+#ifdef PRK_PROBE_NO_WAIT
+        done = true;         // timing probe (wrong results by construction): nobody waits for the vote, the winner rotates
+#endif
         unsigned long long x0 = 0, x1 = 0;
         for (;;)
         {
@@ -560,6 +642,9 @@ __global__ __launch_bounds__(BLOCK, (W > 40 ? 1 : 2)) void ramx_persistent_kerne
         v[1] = (long long)(t1 & (PRK_TICKET - 1)) - (long long)(t1 >> 54) * (long long)PRK_BIAS;
         v[2] = (long long)(t2 & (PRK_TICKET - 1)) - (long long)(t2 >> 54) * (long long)PRK_BIAS;
         v[3] = (long long)(t3 & (PRK_TICKET - 1)) - (long long)(t3 >> 54) * (long long)PRK_BIAS;
+#ifdef PRK_PROBE_NO_WAIT
+        v[0] = (r & 3) == 0; v[1] = (r & 3) == 1; v[2] = (r & 3) == 2; v[3] = (r & 3) == 3;
+#endif
       }
       if (r == 0)
       {
@@ -676,12 +761,35 @@ __global__ __launch_bounds__(BLOCK, (W > 40 ? 1 : 2)) void ramx_persistent_kerne
       // padding lanes (no flank: their base stream is all N, their vote is masked) must not force the whole wave onto
       // the masked path -- with N not a multiple of 64 that one slow wave would gate every column
       const bool all_in = a.pack_ok && __all((n >= a.Nx) || ((jlo <= 0) && (jhi >= B)));
-      // LEAN (see prk_band_fast): no lane of the wave can contribute more than its cap to the next vote or set a record
       const bool maskhi_ok = a.pack_ok > 1 && r >= W && __all((n >= a.Nx) || (jlo <= 0));
-      const bool lean = lean_now;                      // decided at the end of the previous column (same inputs), see below
+      // LEAN?  (prk_band_fast: no lane can contribute more than its cap to the vote of row r+1 or set a record in row r, and the
+      // wave takes one of the in-bounds fast variants.)  prevBest = best cell of row r-1, high = record after row r-1.  A few
+      // lanes that fail the test (`leaders`) do not keep the wave from LEAN: prk_leader_rows computes their candidate rows.
+      bool lean = false;
+      unsigned long long leaders = 0;
+      if (a.lean_p >= 0 && (all_in || maskhi_ok))
+      {
+        const int capfloor = (high + a.cap) > 0 ? (high + a.cap) : 0;
+        const unsigned long long keep = __ballot((n < a.Nx) && !((prevBest + 2 * a.lean_p <= capfloor) && (prevBest + a.lean_p <= high)));
+        lean = keep == 0;
+        if (all_in && keep != 0 && __popcll(keep) <= a.leader_max) { lean = true; leaders = keep; }
+#ifdef RAMX_PRK_TIMING
+        // behind the first half of the run: columns in which this wave may not run plain LEAN, and the lanes that keep it from it
+        if (2 * r >= a.L && keep != 0) { lstat[0] += 1; lstat[1] += (unsigned)__popcll(keep); }
+#endif
+      }
+#ifdef PRK_PROBE_NO_BAND
+      if (r >= 0) { D.bestF = (int)w[0] & 1023; asm volatile("" : "+v"(M[0]), "+v"(M[B - 1])); }      // timing probe: the column without its band
+      else
+#endif
       if (all_in)
       {
-        if (lean) prk_band_fast<W, BLOCK, false, true>(a.go, a.ge, s_ft, sD, r, 0, w, M, D);
+        if (lean)
+        {
+          prk_band_fast<W, BLOCK, false, true>(a.go, a.ge, s_ft, sD, r, 0, w, M, D);
+          for (unsigned long long rest = leaders; rest != 0; rest &= rest - 1)
+            prk_leader_rows<W, BLOCK>(s_ft, sD, sm.lead[wave], r, __builtin_ctzll(rest), w, M, D);
+        }
         else prk_band<W, false, BLOCK>(a.go, a.ge, s_tab, s_ft, sD, r, w, jlo, jhi, M, D);
       }
       else if (maskhi_ok)
@@ -693,17 +801,6 @@ __global__ __launch_bounds__(BLOCK, (W > 40 ? 1 : 2)) void ramx_persistent_kerne
       prevBest = D.bestF;
       if (D.bestF > high) { high = D.bestF; pos = r + D.jbest - W; }   // ram_extend.c:1140-1150
       if (new_max) { thigh = high; tpos = pos; }                        // :1203-1207
-      // Will column r+1 be a LEAN one for this wave?  (prk_band_fast: no lane can contribute more than its cap to the vote of
-      // row r+2 or set a record in row r+1, and the wave takes one of the in-bounds fast variants.)  Everything the test reads
-      // is final now: prevBest = best cell of row r, high after row r, the bounds of row r+1.
-      {
-        const int jlo1 = jlo - 1, jhi1 = jhi - 1;
-        const bool all_in1 = a.pack_ok && __all((n >= a.Nx) || ((jlo1 <= 0) && (jhi1 >= B)));
-        const bool maskhi1 = a.pack_ok > 1 && r + 1 >= W && __all((n >= a.Nx) || (jlo1 <= 0));
-        const int capfloor = (high + a.cap) > 0 ? (high + a.cap) : 0;
-        lean_now = a.lean_p >= 0 && (all_in1 || maskhi1) &&
-                   __all((n >= a.Nx) || ((prevBest + 2 * a.lean_p <= capfloor) && (prevBest + a.lean_p <= high)));
-      }
       if (n < a.Nx)
       {
         const int capv = high + a.cap;
@@ -745,6 +842,8 @@ __global__ __launch_bounds__(BLOCK, (W > 40 ? 1 : 2)) void ramx_persistent_kerne
   {
 #pragma unroll
     for (int k = 0; k < 6; k++) a.dbg[((size_t)blockIdx.x * WPB + wave) * 8 + k] = tsum[k];
+    a.dbg[((size_t)blockIdx.x * WPB + wave) * 8 + 6] = lstat[0];
+    a.dbg[((size_t)blockIdx.x * WPB + wave) * 8 + 7] = lstat[1];
   }
 #endif
 

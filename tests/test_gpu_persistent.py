@@ -200,6 +200,14 @@ def test_lean_band_switches_on_and_off_exactly(W, matrix, gap, short_frac, monke
         full = _run_device(fs, p, 1, monkeypatch, True)
         monkeypatch.delenv("RAMX_NO_LEAN")
         assert lean[0].persistent == 1 and lean[0].lanes_per_flank == 1
-        assert np.array_equal(lean[1], full[1]) and np.array_equal(lean[2], full[2]) and np.array_equal(lean[3], full[3])
-        for (ca, ha, pa), (cb, hb, pb) in zip(lean[4], full[4]):
-            assert np.array_equal(ca, cb) and (ha, pa) == (hb, pb)
+        runs = [lean]
+        # the leader path (prk_leader_rows: a wave with a few lanes that fail the LEAN test runs LEAN and computes those
+        # lanes' candidate rows and best cell with all its lanes): off, and for any number of such lanes per wave
+        for lm in ("0", "64"):
+            monkeypatch.setenv("RAMX_LEADER_MAX", lm)
+            runs.append(_run_device(fs, p, 1, monkeypatch, True))
+        monkeypatch.delenv("RAMX_LEADER_MAX")
+        for x in runs:
+            assert np.array_equal(x[1], full[1]) and np.array_equal(x[2], full[2]) and np.array_equal(x[3], full[3])
+            for (ca, ha, pa), (cb, hb, pb) in zip(x[4], full[4]):
+                assert np.array_equal(ca, cb) and (ha, pa) == (hb, pb)
