@@ -103,7 +103,7 @@ def test_two_ranks_one_gpu_equal_single_process_oracle():
 
 
 @pytest.mark.parametrize("no_cp", [False, True], ids=["cell-parallel", "lane-per-flank"])
-@pytest.mark.parametrize("W,kind", [(14, "device"), (40, "device"), (20, "host"), (40, "host"), (40, "")])
+@pytest.mark.parametrize("W,kind", [(14, "device"), (40, "device"), (20, "host"), (40, "host"), (40, ""), (80, "device")])
 def test_two_ranks_cross_device_persistent_path(W, kind, no_cp):
     """Same two ranks, but with the mailboxes enabled: each rank runs ONE persistent launch per direction and the
     per-column vote is exchanged from inside the kernels (system-scope stores into every rank's box).  kind "device":
