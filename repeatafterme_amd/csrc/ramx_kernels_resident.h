@@ -117,14 +117,18 @@ struct PArgs
 #ifndef PRK_OOB_GROUP
 #define PRK_OOB_GROUP 2
 #endif
+// cells between scheduling barriers of the fast bands, and the LEAN band's look-ahead: two waves per SIMD (512-thread
+// workgroups) want short groups -- 8 -> 4 cells with the look-ahead at 3: 7.24 -> 7.00 us per column at N = 100,000, groups of 1 or
+// 2 are not better (profiles/r03_ab_sweep*.log) -- a lone wave per SIMD wants the long ones (N = 65,000: 6.2 against 6.9 us,
+// profiles/r03_ab_other_shapes.log)
 #ifndef PRK_FAST_GROUP
-#define PRK_FAST_GROUP 8
+#define PRK_FAST_GROUP(BLOCK) ((BLOCK) >= 512 ? 4 : 8)
 #endif
 #ifndef PRK_FETCH_AHEAD
 #define PRK_FETCH_AHEAD 2
 #endif
 #ifndef PRK_FETCH_AHEAD_LEAN
-#define PRK_FETCH_AHEAD_LEAN 2        // the LEAN band has registers to spare: table rows fetched further ahead
+#define PRK_FETCH_AHEAD_LEAN(BLOCK) ((BLOCK) >= 512 ? 3 : 2)        // the LEAN band has registers to spare
 #endif
 __device__ __forceinline__ int vmax3(int x, int y, int z)   // forced v_max3_i32 (keeps the compiler from re-associating)
 {
@@ -265,7 +269,7 @@ __device__ __forceinline__ void prk_band_fast(const int go_, const int ge_, cons
   // compile-time cell index: the band is generated step by step (no reliance on the loop unroller, whose size limit
   // would otherwise leave the row in scratch memory).  Table rows and the previous row's e are fetched PD steps ahead
   // of their use (a lone wave per SIMD -- one family per workgroup -- has nobody to hide the LDS latency behind).
-  constexpr int PD = LEAN ? PRK_FETCH_AHEAD_LEAN : PRK_FETCH_AHEAD;
+  constexpr int PD = LEAN ? PRK_FETCH_AHEAD_LEAN(BLOCK) : PRK_FETCH_AHEAD;
   unsigned A = 0, Alo = 0;
   int2 rowQ[PD];                                    // {candidate bytes, M[besta][base]} of steps j .. j+PD-1
   // e - m of the previous row, TWO cells per LDS instruction: a lane's dword of cell pair p holds d[2p] | d[2p+1] << 16
@@ -310,7 +314,7 @@ __device__ __forceinline__ void prk_band_fast(const int go_, const int ge_, cons
   auto step = [&](auto jc) __attribute__((always_inline))
   {
     constexpr int j = decltype(jc)::value;
-    if constexpr ((j & (PRK_FAST_GROUP - 1)) == 0)
+    if constexpr ((j & (PRK_FAST_GROUP(BLOCK) - 1)) == 0)
     {
       // pin the accumulators to their group: nothing but data dependences orders pure arithmetic against
       // sched_barrier during instruction selection, and a sunk accumulation keeps every table row alive
