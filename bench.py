@@ -98,7 +98,16 @@ def self_launch(n: int) -> int:
         port = s.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    return subprocess.call(cmd)
+    # The contract is ONE JSON line on stdout: whatever else the ranks' libraries write there (gloo announces its
+    # connections on stdout) goes to stderr instead.
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True)
+    for line in proc.stdout:
+        if line.lstrip().startswith("{"):
+            sys.stdout.write(line)
+            sys.stdout.flush()
+        else:
+            sys.stderr.write(line)
+    return proc.wait()
 
 
 def host_cpu():

@@ -502,6 +502,18 @@ int ramx_extend_alignment(int direction, struct coreAlignment *coreAlign, int **
 }
 
 
+/* batch mode's host passes over every family's library (fingerprints; the copy into the concatenated library): by family, threaded */
+struct batch_lib_ctx { const ramx_family *fam; uint64_t *fps; const uint64_t *at_of; int8_t *lib; int do_fp; };
+static void batch_lib_range(int lo, int hi, void *user)
+{
+  const struct batch_lib_ctx *c = (const struct batch_lib_ctx *)user;
+  for (int f = lo; f < hi; f++)
+  {
+    if (c->fps) c->fps[f] = c->do_fp ? fingerprint(c->fam[f].sequence, c->fam[f].seq_len) : 0;
+    if (c->lib && c->fam[f].seq_len) memcpy(c->lib + c->at_of[f], c->fam[f].sequence, c->fam[f].seq_len);
+  }
+}
+
 /*
  * Batch mode: many families, one launch (include/ramx.h).  Libraries are concatenated into one device buffer,
  * every family's flanks are padded to a multiple of 64 with empty flanks, results are written back per family
@@ -516,6 +528,9 @@ int ramx_extend_batch(int direction, ramx_family *fam, int32_t F, const ramx_par
   if (!d) { free(own); return RAMX_ERR_NO_DEVICE; }
   const int W = p->bandwidth, L = p->L;
   int rc = RAMX_OK;
+  const int timing = getenv("RAMX_TIMING") != NULL;
+  double tph = timing ? wall_ms() : 0;
+#define BATCH_PHASE(name) do { if (timing) { const double t_ = wall_ms(); fprintf(stderr, "RAMX_TIMING     batch %-26s %8.3f ms\n", name, t_ - tph); tph = t_; } } while (0)
   /* which families can the batch kernel take? */
   /* every band width and gap sign has a family kernel (register-resident for W = 14/20/40 with non-positive
    * penalties, streaming otherwise); only families above one workgroup (512 flanks) go one by one */
@@ -538,9 +553,13 @@ int ramx_extend_batch(int direction, ramx_family *fam, int32_t F, const ramx_par
   for (int f = 0; f < F; f++) { at_of[f] = total_len; total_len += fam[f].seq_len; }
   int lib_cached = (g_lib_ptr == (const int8_t *)&g_bl_n) && g_bl_n == F && g_lib_len == total_len && total_len <= RAMX_FP_MAX;
   uint64_t *fps = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)(F ? F : 1));
-  for (int f = 0; f < F; f++) fps[f] = total_len <= RAMX_FP_MAX ? fingerprint(fam[f].sequence, fam[f].seq_len) : 0;
+  {
+    struct batch_lib_ctx bc = { fam, fps, at_of, NULL, total_len <= RAMX_FP_MAX };
+    ramx_parallel_for(F, 8, batch_lib_range, &bc);       /* ~10 GB/s per thread: 100 MB of families cost 10 ms on one */
+  }
   for (int f = 0; f < F && lib_cached; f++)
     if (g_bl_ptr[f] != fam[f].sequence || g_bl_len[f] != fam[f].seq_len || g_bl_fp[f] != fps[f]) lib_cached = 0;
+  BATCH_PHASE("library fingerprints");
   int8_t *lib = lib_cached ? NULL : (int8_t *)malloc(total_len ? total_len : 1);
   ramx_flank *fl = (ramx_flank *)malloc(sizeof(ramx_flank) * (total_pad ? total_pad : 1));
   int32_t *map = (int32_t *)malloc(sizeof(int32_t) * (total_pad ? total_pad : 1));
@@ -550,8 +569,11 @@ int ramx_extend_batch(int direction, ramx_family *fam, int32_t F, const ramx_par
   size_t fpos = 0;
   int nb = 0;
   if (lib)
-    for (int f = 0; f < F; f++)
-      if (fam[f].seq_len) memcpy(lib + at_of[f], fam[f].sequence, fam[f].seq_len);
+  {
+    struct batch_lib_ctx bc = { fam, NULL, at_of, lib, 0 };
+    ramx_parallel_for(F, 8, batch_lib_range, &bc);
+  }
+  BATCH_PHASE("library copy");
   for (int f = 0; f < F; f++)
   {
     if (!take[f]) continue;
@@ -565,6 +587,7 @@ int ramx_extend_batch(int direction, ramx_family *fam, int32_t F, const ramx_par
     free(tmp); free(tmap);
     nb++;
   }
+  BATCH_PHASE("resolve flanks");
   if (nb > 0)
   {
     ramx_run_info *binfo = (ramx_run_info *)calloc((size_t)nb, sizeof(ramx_run_info));
@@ -586,7 +609,9 @@ int ramx_extend_batch(int direction, ramx_family *fam, int32_t F, const ramx_par
         g_lib_len = total_len;
       }
     }
+    BATCH_PHASE("library upload");
     if (rc == RAMX_OK) rc = ramx_dev_run_families(d, fl, (int32_t)fpos, first, count, nb, p, binfo, cons, th, tp);
+    BATCH_PHASE("run families (device)");
     if (rc == RAMX_OK)
     {
       for (int b = 0; b < nb; b++)
@@ -613,6 +638,7 @@ int ramx_extend_batch(int direction, ramx_family *fam, int32_t F, const ramx_par
       }
     }
     free(binfo); free(cons); free(th); free(tp);
+    BATCH_PHASE("write-back");
   }
   /* families the batch kernel cannot take (other band widths, positive penalties, > 512 flanks): one by one */
   for (int f = 0; f < F && rc == RAMX_OK; f++)

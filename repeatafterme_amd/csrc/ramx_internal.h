@@ -32,6 +32,9 @@ int ramx_host_threads(long items, long min_items_per_thread);
 #define RAMX_PAR_MAX_OUTS 4
 typedef void (*ramx_chunk_fn)(int lo, int hi, FILE **outs, void *user);
 void ramx_parallel_chunks(int n, int n_outs, FILE **real_outs, ramx_chunk_fn fn, void *user);
+/* fn(lo, hi, user) over [0, n) on the host's cores, at most one thread per min_items items */
+typedef void (*ramx_range_fn)(int lo, int hi, void *user);
+void ramx_parallel_for(int n, long min_items, ramx_range_fn fn, void *user);
 
 /* -vvvv support (reference ram_extend.c:992-1090, 1134-1214): with this callback set a direction runs one column launch at a
  * time (full candidate recurrence) and hands over, after the boundary launch (row = -1) and after every executed row: per

@@ -77,3 +77,29 @@ void ramx_parallel_chunks(int n, int n_outs, FILE **real_outs, ramx_chunk_fn fn,
       }
   free(jobs); free(tid);
 }
+
+/* fn(lo, hi, user) over [0, n) on the host's cores (at most 16; one thread per min_items items; RAMX_HOST_THREADS overrides) */
+struct for_job { int lo, hi; ramx_range_fn fn; void *user; };
+static void *for_worker(void *arg)
+{
+  struct for_job *j = (struct for_job *)arg;
+  j->fn(j->lo, j->hi, j->user);
+  return NULL;
+}
+void ramx_parallel_for(int n, long min_items, ramx_range_fn fn, void *user)
+{
+  const int T = ramx_host_threads(n, min_items);
+  if (T <= 1 || n <= 0) { if (n > 0) fn(0, n, user); return; }
+  struct for_job *jobs = (struct for_job *)calloc((size_t)T, sizeof(*jobs));
+  pthread_t *tid = (pthread_t *)calloc((size_t)T, sizeof(*tid));
+  for (int t = 0; t < T; t++)
+  {
+    jobs[t].lo = (int)((long long)n * t / T); jobs[t].hi = (int)((long long)n * (t + 1) / T);
+    jobs[t].fn = fn; jobs[t].user = user;
+  }
+  for (int t = 1; t < T; t++)
+    if (pthread_create(&tid[t], NULL, for_worker, &jobs[t]) != 0) { for_worker(&jobs[t]); tid[t] = 0; }
+  for_worker(&jobs[0]);
+  for (int t = 1; t < T; t++) if (tid[t]) pthread_join(tid[t], NULL);
+  free(jobs); free(tid);
+}
