@@ -320,6 +320,167 @@ __global__ __launch_bounds__(BLOCK, 1) void pk16_kernel_il(Args a)
   }
 }
 
+// ---- TWO CELLS of ONE flank per register (lane = flank, two waves per SIMD as in the product) -----------------------------------
+// R[k] = (m[2k], m[2k+1]) relative to the flank's base: the row is 41 registers instead of 81.  Chain-free part two cells per
+// instruction (sub, sub + go); the insertion chain one cell per v_max3_i16 / v_add_i16 with op_sel half selects; the chain
+// register C_k = (e[2k-1], e[2k]) is at once the operand of the packed m = max(sub, Pe, C_k) and -- stored as dword k -- the
+// pair (e[2j+1], e[2j+2]) that pair j = k-1 of the NEXT row needs as its deletion term: e itself fits int16 here, so no d row.
+// Score pairs: byte k of the phase-aligned base word is (code[2k+1] << 4 | code[2k]) and indexes the 256-entry pair table.
+constexpr int BLOCKC = 512, NP = (B + 1) / 2, NWIN8 = (B + 7) / 8 + 2;
+
+__device__ __forceinline__ int max3_lll(int a, int b, int c) { int d; asm("v_max3_i16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+__device__ __forceinline__ int max3_hhh(int a, int b, int c) { int d; asm("v_max3_i16 %0, %1, %2, %3 op_sel:[1,1,1,0]" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+__device__ __forceinline__ void add_to_hi(int &dst, int a, int b) { asm("v_add_i16 %0, %1, %2 op_sel:[0,0,1]" : "+v"(dst) : "v"(a), "v"(b)); }
+__device__ __forceinline__ int add_lo(int a, int b) { int d; asm("v_add_i16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+
+template <int PT>
+__global__ __launch_bounds__(BLOCKC, 1) void pkc_kernel(Args a)
+{
+  __shared__ struct { int T[256]; int E[NP * BLOCKC]; } sh;
+  int *const sT = sh.T;
+  const int f = blockIdx.x * BLOCKC + threadIdx.x;
+  const bool live = f < a.lanes;
+  const int fl = live ? f : 0;
+  int R[NP];
+  const int go2 = (a.go & 0xffff) | (a.go << 16), ge2 = (a.ge & 0xffff) | (a.ge << 16);
+  const int neg2 = (int)0x80008000u;
+  int *myE = sh.E + threadIdx.x;
+  // start state: m = 0, d = go + ge everywhere, i.e. e = go + ge
+#pragma unroll
+  for (int k = 0; k < NP; k++) { R[k] = 0; myE[k * BLOCKC] = ((a.go + a.ge) & 0xffff) | ((a.go + a.ge) << 16); }
+  int base = 0;
+  long long sum = 0;
+  unsigned w[NWIN8];
+#pragma unroll
+  for (int k = 0; k < NWIN8; k++) w[k] = a.words[(size_t)k * a.lanes + fl];
+  unsigned wnext = a.words[(size_t)NWIN8 * a.lanes + fl];
+  int nreb = 0;
+  const char *tb = reinterpret_cast<const char *>(&sT[0]);
+  for (int r = 0; r < a.C; r++)
+  {
+    if ((r & 7) == 0 && r > 0)
+    {
+#pragma unroll
+      for (int k = 0; k + 1 < NWIN8; k++) w[k] = w[k + 1];
+      w[NWIN8 - 1] = wnext;
+      wnext = a.words[(size_t)(NWIN8 + (r >> 3)) * a.lanes + fl];
+    }
+    int eQ[PT];                          // previous row's chain registers of the first pairs (their deletion terms)
+#pragma unroll
+    for (int k = 0; k < PT; k++) eQ[k] = k + 1 < NP ? myE[(k + 1) * BLOCKC] : neg2;
+    __syncthreads();
+    if (threadIdx.x < 256)
+    {
+      const int c = winner_of(r), i = threadIdx.x;
+      const int sa = a.tab[c * 16 + (i & 15)], sb = a.tab[c * 16 + (i >> 4)];
+      sT[i] = (sa & 0xffff) | (sb << 16);
+    }
+    __syncthreads();
+    const int ph4 = 4 * (r & 7);
+    int C = neg2, best = neg2;           // C.lo = e of the cell before the pair
+    unsigned A = 0;
+    int tQ[PT];
+    auto lookup = [&](auto kc) __attribute__((always_inline))
+    {
+      constexpr int k = decltype(kc)::value;
+      if constexpr ((k & 3) == 0) A = __builtin_amdgcn_alignbit(w[(k >> 2) + 1], w[k >> 2], ph4);
+      return *reinterpret_cast<const int *>(tb + byte_x4<(k & 3)>(A));
+    };
+    sfor([&](auto kc) __attribute__((always_inline)) { tQ[decltype(kc)::value] = lookup(kc); }, std::make_integer_sequence<int, PT>{});
+    sfor([&](auto kc) __attribute__((always_inline))
+    {
+      constexpr int k = decltype(kc)::value;
+      if constexpr ((k & 1) == 0)
+      {
+        asm volatile("" ::"v"(best), "v"(C));
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      const int S = tQ[0], PeP = eQ[0];
+#pragma unroll
+      for (int q = 0; q + 1 < PT; q++) { tQ[q] = tQ[q + 1]; eQ[q] = eQ[q + 1]; }
+      if constexpr (k + PT < NP) tQ[PT - 1] = lookup(std::integral_constant<int, (k + PT < NP ? k + PT : 0)>{});
+      if constexpr (k + 1 + PT < NP) eQ[PT - 1] = myE[(k + 1 + PT) * BLOCKC];
+      else eQ[PT - 1] = neg2;
+      const int sub = as_int(as_s2(R[k]) + as_s2(S));
+      const int sg = as_int(as_s2(sub) + as_s2(go2));
+      const int t = max3_lll(sg, PeP, C);                       // max(sub + go, Pe, e of the cell before), cell 2k
+      add_to_hi(C, t, ge2);                                     // C = (e[2k-1], e[2k])
+      int m = as_int(pmax(pmax(as_s2(sub), as_s2(PeP)), as_s2(C)));
+      if constexpr (k > 0) myE[k * BLOCKC] = C;
+      if constexpr (2 * k + 1 < B)
+      {
+        const int t2 = max3_hhh(sg, PeP, C);                    // cell 2k+1
+        C = add_lo(t2, ge2);                                    // next pair's chain register: lo = e[2k+1]
+      }
+      else m = (m & 0xffff) | (int)0x80000000u;                 // cell 81 does not exist
+      R[k] = m;
+      best = as_int(pmax(as_s2(best), as_s2(m)));
+    }, std::make_integer_sequence<int, NP>{});
+    const s2 bp = as_s2(best);
+    const int bst = bp.x > bp.y ? bp.x : bp.y;
+    sum += base + bst;
+    if ((r & 15) == 15)
+    {
+      const bool far = bst > 8000 || bst < -8000;
+      if (__builtin_amdgcn_ballot_w64(far) != 0 || a.rebases)
+      {
+        const s2 bb = { (short)bst, (short)bst };
+#pragma unroll
+        for (int k = 0; k < NP; k++) R[k] = as_int(as_s2(R[k]) - bb);
+#pragma unroll
+        for (int k = 1; k < NP; k++) myE[k * BLOCKC] = as_int(as_s2(myE[k * BLOCKC]) - bb);
+        base += bst;
+        nreb++;
+      }
+    }
+  }
+  if (live)
+  {
+#pragma unroll
+    for (int k = 0; k < NP; k++)
+    {
+      a.rows[(size_t)f * B + 2 * k] = base + (int)as_s2(R[k]).x;
+      if (2 * k + 1 < B) a.rows[(size_t)f * B + 2 * k + 1] = base + (int)as_s2(R[k]).y;
+    }
+    a.bestsum[f] = sum;
+    if ((threadIdx.x & 63) == 0 && nreb) atomicAdd(a.nrebase, nreb);
+  }
+}
+
+// 32-bit checker for the nibble layout (lane = flank, eight codes per word)
+__global__ __launch_bounds__(BLOCK) void ref32c_kernel(Args a)
+{
+  const int f = blockIdx.x * BLOCK + threadIdx.x;
+  if (f >= a.lanes) return;
+  int M[B], D[B];
+  for (int j = 0; j < B; j++) { M[j] = 0; D[j] = a.go + a.ge; }
+  long long sum = 0;
+  for (int r = 0; r < a.C; r++)
+  {
+    const int c = winner_of(r);
+    int eC = NEG32, best = NEG32;
+    for (int j = 0; j < B; j++)
+    {
+      const int p = r + j;
+      const unsigned word = a.words[(size_t)(p >> 3) * a.lanes + f];
+      const int code = (word >> (4 * (p & 7))) & 15;
+      const int sF = a.tab[c * 16 + code];
+      const int Pe = j + 1 < B ? M[j + 1] + D[j + 1] : NEG32;
+      const int sub = M[j] + sF;
+      const int t = max(eC, Pe);
+      const int m = max(sub, t);
+      const int e = max(sub + a.go, t) + a.ge;
+      M[j] = m;
+      D[j] = e - m;
+      best = max(best, m);
+      eC = e;
+    }
+    sum += best;
+  }
+  for (int j = 0; j < B; j++) a.rows[(size_t)f * B + j] = M[j];
+  a.bestsum[f] = sum;
+}
+
 // ---- plain 32-bit evaluation of the same recurrence, one flank per lane (the checker; not tuned) -------------------------------
 __global__ __launch_bounds__(BLOCK) void ref32_kernel(Args a)
 {
@@ -463,6 +624,74 @@ int main(int argc, char **argv)
     printf("pass %d  %d workgroups x %d threads = %d flanks, %d columns: %.3f us per column (%.2f ms), %d wave-rebases; cells differing from the "
            "32-bit rows %zu of %zu, best-sum mismatches %zu of %zu; final rows span [%d, %d], widest row %d\n",
            pass, blocks, BLOCK, 2 * lanes, C, best_ms * 1e3 / C, best_ms, nreb, badc, r0.size(), bads, s0.size(), lo, hi, spread);
+    CHK(hipFree(d_words));
+    for (int v = 0; v < 2; v++) { CHK(hipFree(d_rows[v])); CHK(hipFree(d_sum[v])); }
+  }
+  // ---- two cells per register, lane = flank, 196 x 512 (two waves per SIMD) ------------------------------------------------------
+  for (int pass = 0; pass < 2; pass++)
+  {
+    const int blocks = 196, flanks = blocks * BLOCKC;
+    const int nwords = NWIN8 + C / 8 + 4;
+    std::vector<unsigned> words((size_t)nwords * flanks);
+    for (size_t k = 0; k < (size_t)nwords; k++)
+      for (int l = 0; l < flanks; l++)
+      {
+        unsigned wv = 0;
+        for (int q = 0; q < 8; q++)
+        {
+          const int p = (int)k * 8 + q;
+          unsigned ca;
+          if (pass == 1) { const int c = p >= W ? winner_of(p - W) : 0; ca = rnd() % 9 ? (unsigned)c : rnd() & 15; }
+          else ca = rnd() % 50 ? rnd() & 3 : rnd() & 15;
+          wv |= ca << (4 * q);
+        }
+        words[k * flanks + l] = wv;
+      }
+    unsigned *d_words; int *d_rows[2]; long long *d_sum[2];
+    CHK(hipMalloc(&d_words, words.size() * 4));
+    CHK(hipMemcpy(d_words, words.data(), words.size() * 4, hipMemcpyHostToDevice));
+    for (int v = 0; v < 2; v++) { CHK(hipMalloc(&d_rows[v], (size_t)flanks * B * 4)); CHK(hipMalloc(&d_sum[v], (size_t)flanks * 8)); }
+    Args a = { d_words, d_tab, d_rows[0], d_sum[0], flanks, C, go, ge, 0, d_nreb };
+    hipEvent_t e0, e1;
+    CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
+    typedef void (*kern_t)(Args);
+    static const struct { kern_t k; const char *name; } variants[] = { { pkc_kernel<2>, "PT 2" }, { pkc_kernel<4>, "PT 4" }, { pkc_kernel<6>, "PT 6" } };
+    float best_ms = 1e30f;
+    for (int v = 0; v < 3; v++)
+    {
+      float vms = 1e30f;
+      hipLaunchKernelGGL(variants[v].k, dim3(blocks), dim3(BLOCKC), 0, 0, a);
+      CHK(hipDeviceSynchronize());
+      for (int rep = 0; rep < 3; rep++)
+      {
+        CHK(hipMemset(d_nreb, 0, 4));
+        CHK(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL(variants[v].k, dim3(blocks), dim3(BLOCKC), 0, 0, a);
+        CHK(hipEventRecord(e1, 0));
+        CHK(hipEventSynchronize(e1));
+        float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
+        if (ms < vms) vms = ms;
+      }
+      printf("  two cells per register, %s: %.3f us per column\n", variants[v].name, vms * 1e3 / C);
+      if (vms < best_ms) best_ms = vms;
+    }
+    int nreb = 0;
+    CHK(hipMemcpy(&nreb, d_nreb, 4, hipMemcpyDeviceToHost));
+    Args b = a; b.rows = d_rows[1]; b.bestsum = d_sum[1];
+    hipLaunchKernelGGL(ref32c_kernel, dim3((flanks + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, 0, b);
+    CHK(hipDeviceSynchronize());
+    std::vector<int> r0((size_t)flanks * B), r1(r0.size());
+    std::vector<long long> s0((size_t)flanks), s1(s0.size());
+    CHK(hipMemcpy(r0.data(), d_rows[0], r0.size() * 4, hipMemcpyDeviceToHost));
+    CHK(hipMemcpy(r1.data(), d_rows[1], r1.size() * 4, hipMemcpyDeviceToHost));
+    CHK(hipMemcpy(s0.data(), d_sum[0], s0.size() * 8, hipMemcpyDeviceToHost));
+    CHK(hipMemcpy(s1.data(), d_sum[1], s1.size() * 8, hipMemcpyDeviceToHost));
+    size_t badc = 0, bads = 0;
+    for (size_t i = 0; i < r0.size(); i++) badc += r0[i] != r1[i];
+    for (size_t i = 0; i < s0.size(); i++) bads += s0[i] != s1[i];
+    printf("cells pass %d  %d workgroups x %d threads = %d flanks (two waves per SIMD), %d columns: %.3f us per column, %d wave-rebases; cells "
+           "differing from the 32-bit rows %zu of %zu, best-sum mismatches %zu of %zu\n",
+           pass, blocks, BLOCKC, flanks, C, best_ms * 1e3 / C, nreb, badc, r0.size(), bads, s0.size());
     CHK(hipFree(d_words));
     for (int v = 0; v < 2; v++) { CHK(hipFree(d_rows[v])); CHK(hipFree(d_sum[v])); }
   }
