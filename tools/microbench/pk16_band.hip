@@ -54,6 +54,7 @@ struct Args
   long long *bestsum;         // out: [2 * lanes] sum over the rows of the best cell
   int lanes, C, go, ge, rebases;
   int *nrebase;               // out: rebase events (waves)
+  long long *candsum;         // out (full band): sum over rows and candidates of the candidate rows' best cells
 };
 
 // ---- packed: two flanks per lane ---------------------------------------------------------------------------------------
@@ -333,10 +334,10 @@ __device__ __forceinline__ int max3_hhh(int a, int b, int c) { int d; asm("v_max
 __device__ __forceinline__ void add_to_hi(int &dst, int a, int b) { asm("v_add_i16 %0, %1, %2 op_sel:[0,0,1]" : "+v"(dst) : "v"(a), "v"(b)); }
 __device__ __forceinline__ int add_lo(int a, int b) { int d; asm("v_add_i16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
 
-template <int PT>
+template <int PT, bool FULL>
 __global__ __launch_bounds__(BLOCKC, 1) void pkc_kernel(Args a)
 {
-  __shared__ struct { int T[256]; int E[NP * BLOCKC]; } sh;
+  __shared__ struct { int T[256]; int4 T4[FULL ? 256 : 1]; int E[NP * BLOCKC]; } sh;
   int *const sT = sh.T;
   const int f = blockIdx.x * BLOCKC + threadIdx.x;
   const bool live = f < a.lanes;
@@ -349,7 +350,18 @@ __global__ __launch_bounds__(BLOCKC, 1) void pkc_kernel(Args a)
 #pragma unroll
   for (int k = 0; k < NP; k++) { R[k] = 0; myE[k * BLOCKC] = ((a.go + a.ge) & 0xffff) | ((a.go + a.ge) << 16); }
   int base = 0;
-  long long sum = 0;
+  long long sum = 0, csum = 0;
+  if constexpr (FULL)
+  {
+    // the four candidates' score pairs of a code pair, once per launch: one ds_read_b128 per cell pair
+    if (threadIdx.x < 256)
+    {
+      const int i = threadIdx.x;
+      int q[4];
+      for (int c = 0; c < 4; c++) q[c] = (a.tab[c * 16 + (i & 15)] & 0xffff) | (a.tab[c * 16 + (i >> 4)] << 16);
+      sh.T4[i] = make_int4(q[0], q[1], q[2], q[3]);
+    }
+  }
   unsigned w[NWIN8];
 #pragma unroll
   for (int k = 0; k < NWIN8; k++) w[k] = a.words[(size_t)k * a.lanes + fl];
@@ -378,13 +390,23 @@ __global__ __launch_bounds__(BLOCKC, 1) void pkc_kernel(Args a)
     __syncthreads();
     const int ph4 = 4 * (r & 7);
     int C = neg2, best = neg2;           // C.lo = e of the cell before the pair
+    int bA[4] = { neg2, neg2, neg2, neg2 }, maxE = neg2, Rprev = neg2;
     unsigned A = 0;
     int tQ[PT];
+    int cQ[FULL ? PT : 1][4];
+    const char *tb4 = reinterpret_cast<const char *>(&sh.T4[0]);
     auto lookup = [&](auto kc) __attribute__((always_inline))
     {
       constexpr int k = decltype(kc)::value;
       if constexpr ((k & 3) == 0) A = __builtin_amdgcn_alignbit(w[(k >> 2) + 1], w[k >> 2], ph4);
-      return *reinterpret_cast<const int *>(tb + byte_x4<(k & 3)>(A));
+      const unsigned off = byte_x4<(k & 3)>(A);
+      if constexpr (FULL)
+      {
+        const int4 v4 = *reinterpret_cast<const int4 *>(tb4 + 4 * off);
+        constexpr int qi = k < PT ? k : PT - 1;
+        cQ[qi][0] = v4.x; cQ[qi][1] = v4.y; cQ[qi][2] = v4.z; cQ[qi][3] = v4.w;
+      }
+      return *reinterpret_cast<const int *>(tb + off);
     };
     sfor([&](auto kc) __attribute__((always_inline)) { tQ[decltype(kc)::value] = lookup(kc); }, std::make_integer_sequence<int, PT>{});
     sfor([&](auto kc) __attribute__((always_inline))
@@ -392,12 +414,15 @@ __global__ __launch_bounds__(BLOCKC, 1) void pkc_kernel(Args a)
       constexpr int k = decltype(kc)::value;
       if constexpr ((k & 1) == 0)
       {
-        asm volatile("" ::"v"(best), "v"(C));
+        // pin the accumulators to their group (a sunk accumulation keeps every table row alive, as in prk_band_fast)
+        if constexpr (FULL) asm volatile("" ::"v"(best), "v"(C), "v"(bA[0]), "v"(bA[1]), "v"(bA[2]), "v"(bA[3]), "v"(maxE));
+        else asm volatile("" ::"v"(best), "v"(C));
         __builtin_amdgcn_sched_barrier(0);
       }
       const int S = tQ[0], PeP = eQ[0];
+      const int sc[4] = { cQ[0][0], cQ[0][1], cQ[0][2], cQ[0][3] };
 #pragma unroll
-      for (int q = 0; q + 1 < PT; q++) { tQ[q] = tQ[q + 1]; eQ[q] = eQ[q + 1]; }
+      for (int q = 0; q + 1 < PT; q++) { tQ[q] = tQ[q + 1]; eQ[q] = eQ[q + 1]; if constexpr (FULL) { cQ[q][0] = cQ[q + 1][0]; cQ[q][1] = cQ[q + 1][1]; cQ[q][2] = cQ[q + 1][2]; cQ[q][3] = cQ[q + 1][3]; } }
       if constexpr (k + PT < NP) tQ[PT - 1] = lookup(std::integral_constant<int, (k + PT < NP ? k + PT : 0)>{});
       if constexpr (k + 1 + PT < NP) eQ[PT - 1] = myE[(k + 1 + PT) * BLOCKC];
       else eQ[PT - 1] = neg2;
@@ -406,6 +431,7 @@ __global__ __launch_bounds__(BLOCKC, 1) void pkc_kernel(Args a)
       const int t = max3_lll(sg, PeP, C);                       // max(sub + go, Pe, e of the cell before), cell 2k
       add_to_hi(C, t, ge2);                                     // C = (e[2k-1], e[2k])
       int m = as_int(pmax(pmax(as_s2(sub), as_s2(PeP)), as_s2(C)));
+      const int C_done = C;
       if constexpr (k > 0) myE[k * BLOCKC] = C;
       if constexpr (2 * k + 1 < B)
       {
@@ -415,10 +441,39 @@ __global__ __launch_bounds__(BLOCKC, 1) void pkc_kernel(Args a)
       else m = (m & 0xffff) | (int)0x80000000u;                 // cell 81 does not exist
       R[k] = m;
       best = as_int(pmax(as_s2(best), as_s2(m)));
+      if constexpr (FULL)
+      {
+        // candidate cells 2k-1 and 2k of row r+1: substitution from (m[2k-1], m[2k]) with the codes of steps 2k, 2k+1
+        // (ram_extend.c:1013-1040 through prk_band_fast's t4); their shared deletion term is the running maximum of e
+        int ms = (int)__builtin_amdgcn_alignbit((unsigned)m, (unsigned)Rprev, 16);
+        if constexpr (k == 0) ms = (ms & (int)0xffff0000u) | 0x8000;         // there is no cell -1 ...
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+        {
+          int t = as_int(as_s2(ms) + as_s2(sc[c]));
+          if constexpr (k == 0) t = (t & (int)0xffff0000u) | 0x8000;         // ... and its term must not wrap into range
+          bA[c] = as_int(pmax(as_s2(bA[c]), as_s2(t)));
+        }
+        if constexpr (k > 0) maxE = as_int(pmax(as_s2(maxE), as_s2(C_done)));
+        Rprev = m;
+      }
     }, std::make_integer_sequence<int, NP>{});
     const s2 bp = as_s2(best);
     const int bst = bp.x > bp.y ? bp.x : bp.y;
     sum += base + bst;
+    if constexpr (FULL)
+    {
+      const s2 me = as_s2(maxE);
+      const int mE = me.x > me.y ? me.x : me.y;
+#pragma unroll
+      for (int c = 0; c < 4; c++)
+      {
+        const s2 q = as_s2(bA[c]);
+        int v = q.x > q.y ? q.x : q.y;
+        v = v > mE ? v : mE;
+        csum += base + v;
+      }
+    }
     if ((r & 15) == 15)
     {
       const bool far = bst > 8000 || bst < -8000;
@@ -443,6 +498,7 @@ __global__ __launch_bounds__(BLOCKC, 1) void pkc_kernel(Args a)
       if (2 * k + 1 < B) a.rows[(size_t)f * B + 2 * k + 1] = base + (int)as_s2(R[k]).y;
     }
     a.bestsum[f] = sum;
+    if (FULL) a.candsum[f] = csum;
     if ((threadIdx.x & 63) == 0 && nreb) atomicAdd(a.nrebase, nreb);
   }
 }
@@ -454,16 +510,20 @@ __global__ __launch_bounds__(BLOCK) void ref32c_kernel(Args a)
   if (f >= a.lanes) return;
   int M[B], D[B];
   for (int j = 0; j < B; j++) { M[j] = 0; D[j] = a.go + a.ge; }
-  long long sum = 0;
+  long long sum = 0, csum = 0;
   for (int r = 0; r < a.C; r++)
   {
     const int c = winner_of(r);
-    int eC = NEG32, best = NEG32;
-    for (int j = 0; j < B; j++)
+    int eC = NEG32, best = NEG32, mPrev = NEG32, maxE = NEG32;
+    int bA[4] = { NEG32, NEG32, NEG32, NEG32 };
+    for (int j = 0; j <= B; j++)
     {
       const int p = r + j;
       const unsigned word = a.words[(size_t)(p >> 3) * a.lanes + f];
       const int code = (word >> (4 * (p & 7))) & 15;
+      if (j >= 1)
+        for (int q = 0; q < 4; q++) bA[q] = max(bA[q], mPrev + a.tab[q * 16 + code]);
+      if (j == B) break;
       const int sF = a.tab[c * 16 + code];
       const int Pe = j + 1 < B ? M[j + 1] + D[j + 1] : NEG32;
       const int sub = M[j] + sF;
@@ -473,12 +533,16 @@ __global__ __launch_bounds__(BLOCK) void ref32c_kernel(Args a)
       M[j] = m;
       D[j] = e - m;
       best = max(best, m);
+      if (j >= 1) maxE = max(maxE, e);
+      mPrev = m;
       eC = e;
     }
     sum += best;
+    for (int q = 0; q < 4; q++) csum += max(bA[q], maxE);
   }
   for (int j = 0; j < B; j++) a.rows[(size_t)f * B + j] = M[j];
   a.bestsum[f] = sum;
+  a.candsum[f] = csum;
 }
 
 // ---- plain 32-bit evaluation of the same recurrence, one flank per lane (the checker; not tuned) -------------------------------
@@ -566,7 +630,7 @@ int main(int argc, char **argv)
     CHK(hipMemcpy(d_words, words.data(), words.size() * 4, hipMemcpyHostToDevice));
     for (int v = 0; v < 2; v++) { CHK(hipMalloc(&d_rows[v], (size_t)2 * lanes * B * 4)); CHK(hipMalloc(&d_sum[v], (size_t)2 * lanes * 8)); }
     CHK(hipMemset(d_nreb, 0, 4));
-    Args a = { d_words, d_tab, d_rows[0], d_sum[0], lanes, C, go, ge, 0, d_nreb };
+    Args a = { d_words, d_tab, d_rows[0], d_sum[0], lanes, C, go, ge, 0, d_nreb, nullptr };
     hipEvent_t e0, e1;
     CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
     typedef void (*kern_t)(Args);
@@ -651,13 +715,17 @@ int main(int argc, char **argv)
     CHK(hipMalloc(&d_words, words.size() * 4));
     CHK(hipMemcpy(d_words, words.data(), words.size() * 4, hipMemcpyHostToDevice));
     for (int v = 0; v < 2; v++) { CHK(hipMalloc(&d_rows[v], (size_t)flanks * B * 4)); CHK(hipMalloc(&d_sum[v], (size_t)flanks * 8)); }
-    Args a = { d_words, d_tab, d_rows[0], d_sum[0], flanks, C, go, ge, 0, d_nreb };
+    long long *d_cs[2];
+    for (int v = 0; v < 2; v++) { CHK(hipMalloc(&d_cs[v], (size_t)flanks * 8)); CHK(hipMemset(d_cs[v], 0, (size_t)flanks * 8)); }
+    Args a = { d_words, d_tab, d_rows[0], d_sum[0], flanks, C, go, ge, 0, d_nreb, d_cs[0] };
     hipEvent_t e0, e1;
     CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
     typedef void (*kern_t)(Args);
-    static const struct { kern_t k; const char *name; } variants[] = { { pkc_kernel<2>, "PT 2" }, { pkc_kernel<4>, "PT 4" }, { pkc_kernel<6>, "PT 6" } };
+    static const struct { kern_t k; const char *name; } variants[] = { { pkc_kernel<2, false>, "LEAN PT 2" }, { pkc_kernel<4, false>, "LEAN PT 4" },
+                                                                       { pkc_kernel<6, false>, "LEAN PT 6" }, { pkc_kernel<2, true>, "FULL PT 2" },
+                                                                       { pkc_kernel<4, true>, "FULL PT 4" } };
     float best_ms = 1e30f;
-    for (int v = 0; v < 3; v++)
+    for (int v = 0; v < 5; v++)
     {
       float vms = 1e30f;
       hipLaunchKernelGGL(variants[v].k, dim3(blocks), dim3(BLOCKC), 0, 0, a);
@@ -677,7 +745,7 @@ int main(int argc, char **argv)
     }
     int nreb = 0;
     CHK(hipMemcpy(&nreb, d_nreb, 4, hipMemcpyDeviceToHost));
-    Args b = a; b.rows = d_rows[1]; b.bestsum = d_sum[1];
+    Args b = a; b.rows = d_rows[1]; b.bestsum = d_sum[1]; b.candsum = d_cs[1];
     hipLaunchKernelGGL(ref32c_kernel, dim3((flanks + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, 0, b);
     CHK(hipDeviceSynchronize());
     std::vector<int> r0((size_t)flanks * B), r1(r0.size());
@@ -686,12 +754,18 @@ int main(int argc, char **argv)
     CHK(hipMemcpy(r1.data(), d_rows[1], r1.size() * 4, hipMemcpyDeviceToHost));
     CHK(hipMemcpy(s0.data(), d_sum[0], s0.size() * 8, hipMemcpyDeviceToHost));
     CHK(hipMemcpy(s1.data(), d_sum[1], s1.size() * 8, hipMemcpyDeviceToHost));
-    size_t badc = 0, bads = 0;
+    std::vector<long long> c0((size_t)flanks), c1(c0.size());
+    CHK(hipMemcpy(c0.data(), d_cs[0], c0.size() * 8, hipMemcpyDeviceToHost));
+    CHK(hipMemcpy(c1.data(), d_cs[1], c1.size() * 8, hipMemcpyDeviceToHost));
+    size_t badc = 0, bads = 0, badk = 0;
     for (size_t i = 0; i < r0.size(); i++) badc += r0[i] != r1[i];
     for (size_t i = 0; i < s0.size(); i++) bads += s0[i] != s1[i];
+    for (size_t i = 0; i < c0.size(); i++) badk += c0[i] != c1[i];
+    printf("  candidate-row sums (last variant = FULL) mismatching: %zu of %zu\n", badk, c0.size());
     printf("cells pass %d  %d workgroups x %d threads = %d flanks (two waves per SIMD), %d columns: %.3f us per column, %d wave-rebases; cells "
            "differing from the 32-bit rows %zu of %zu, best-sum mismatches %zu of %zu\n",
            pass, blocks, BLOCKC, flanks, C, best_ms * 1e3 / C, nreb, badc, r0.size(), bads, s0.size());
+    for (int v = 0; v < 2; v++) CHK(hipFree(d_cs[v]));
     CHK(hipFree(d_words));
     for (int v = 0; v < 2; v++) { CHK(hipFree(d_rows[v])); CHK(hipFree(d_sum[v])); }
   }
