@@ -740,6 +740,20 @@ static int prk_run(ramx_dev *d, const KArgs &a, int L, bool *used)
   pa.lean_p = lean_p_of(pa.tab, a.go, a.ge);
   // a leader costs its wave ~150 instructions in prk_leader_rows, the full band 640 more than LEAN; RAMX_LEADER_MAX=0 switches
   // the leader path off (A/B and tests), larger values exercise it on waves with many leaders
+  // packed LEAN rows (prk_band_pk): two cells per register in int16 relative to a per-flank base.  A cell lies at most
+  // max(PRK_PK_ENTER + 2W (|min| + |ge|) + |go|,  2W (P + |min| + |ge|) + |go| + |ge|) below its row's best cell, the base is at most
+  // PRK_PK_REBASE + 16 max(P, |min|) away from that, and sub + go / e need |go| + |ge| + P more: all of it must fit int16
+  pa.pk_ok = 0;
+  if (pa.lean_p >= 0 && pa.pack_ok && W <= 40 && getenv("RAMX_NO_PK") == NULL)
+  {
+    int mn = 0;
+    for (int c = 0; c < RAMX_NCLASS; c++)
+      for (int k = 0; k < 4; k++) if (pa.tab[c][k] < mn) mn = pa.tab[c][k];
+    const long long P = pa.lean_p, m = -(long long)mn, go_ = -(long long)a.go, ge_ = -(long long)a.ge;
+    const long long below = std::max(10000LL + 2LL * W * (m + ge_) + go_, 2LL * W * (P + m + ge_) + go_ + ge_);
+    const long long span = below + 8000LL + 16LL * std::max(P, m) + go_ + ge_ + P;
+    pa.pk_ok = span < 32000LL ? 1 : 0;
+  }
   { const char *lm = getenv("RAMX_LEADER_MAX"); pa.leader_max = lm ? atoi(lm) : 3; if (pa.leader_max < 0) pa.leader_max = 0; if (pa.leader_max > 64) pa.leader_max = 64; }
   HIPCHK(hipMemsetAsync(d->d_vote, 0, PRK_NSETS * NSHARD * sizeof(PShard), d->stream));
   HIPCHK(hipMemsetAsync(d->d_err, 0, 64, d->stream));
