@@ -1655,6 +1655,7 @@ extern "C" int ramx_dev_run_direction(ramx_dev *d, ramx_run_info *info)
     info->persistent = persistent ? 1 : 0;
     info->lanes_per_flank = lanes;
     info->respeculated_rows = cp_done ? f.besta : 0;
+    info->packed_rows = (persistent && !cp_done) ? f.besta : 0;
   }
   return RAMX_OK;
 }

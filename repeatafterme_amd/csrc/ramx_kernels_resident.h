@@ -684,14 +684,11 @@ __device__ __forceinline__ void prk_leader_rows_pk(const FastTabs &ft, const int
   const int lane = threadIdx.x & 63;
   if (lane == leader)
   {
+    // the packed registers as they are (W + 1 stores, no arithmetic on the wave that every workgroup waits for)
 #pragma unroll
-    for (int k = 0; k < NP; k++)
-    {
-      scr[2 * k] = base + (int)(short)R[k];
-      if (2 * k + 1 < B) scr[2 * k + 1] = base + (R[k] >> 16);
-    }
+    for (int k = 0; k < NP; k++) scr[k] = R[k];
 #pragma unroll
-    for (int k = 0; k < NW; k++) scr[B + k] = (int)w[k];
+    for (int k = 0; k < NW; k++) scr[NP + k] = (int)w[k];
   }
   __builtin_amdgcn_wave_barrier();
   const int ph = (r + 8) & 7;
@@ -706,9 +703,10 @@ __device__ __forceinline__ void prk_leader_rows_pk(const FastTabs &ft, const int
     const int k = lane + 64 * h;
     const bool ok = k < B;
     const int kk = ok ? k : 0;
-    const int m = scr[kk];
+    const int mw = scr[kk >> 1];
+    const int m = lbase + ((kk & 1) ? (mw >> 16) : (int)(short)mw);
     const int g = kk + 1 + ph;
-    const unsigned cls = ((unsigned)scr[B + (g >> 3)] >> (4 * (g & 7))) & 15u;
+    const unsigned cls = ((unsigned)scr[NP + (g >> 3)] >> (4 * (g & 7))) & 15u;
     const int sv = ft.row[cls][0];
     if (ok)
     {
@@ -776,6 +774,7 @@ __global__ __launch_bounds__(BLOCK, (W > 40 ? 1 : 2)) void ramx_persistent_kerne
   int high, pos, thigh = 0, tpos = 0;
   int prevBest = 0x3fffffff;             // best cell of the previous row (LEAN test): unknown before the first band of this launch
   int leanrun = 0;                       // consecutive in-bounds LEAN columns of this wave (scalar)
+  int pk_cols = 0;                       // columns this wave ran on the packed row (reported for wave 0 of workgroup 0)
   {
 #pragma unroll
     for (int q = 0; q < W; q++)
@@ -1284,6 +1283,7 @@ __global__ __launch_bounds__(BLOCK, (W > 40 ? 1 : 2)) void ramx_persistent_kerne
                 default: rel = prk_band_pk<W, BLOCK, 3>(a.go, a.ge, sm.pk, sE, r, w, R); break;
               }
               D.bestF = pbase + rel;
+              pk_cols++;
               for (unsigned long long rest = leaders; rest != 0; rest &= rest - 1)
                 prk_leader_rows_pk<W, BLOCK>(s_ft, sE, sm.lead[wave], r, __builtin_ctzll(rest), pbase, w, R, D);
               if ((r & 15) == 15 && __any(rel > PRK_PK_REBASE || rel < -PRK_PK_REBASE))
@@ -1369,7 +1369,7 @@ __global__ __launch_bounds__(BLOCK, (W > 40 ? 1 : 2)) void ramx_persistent_kerne
   if (blockIdx.x == 0 && threadIdx.x == 0)
   {
     RamxCtl o;
-    o.max_ext = max_ext; o.max_row = max_row; o.stopped = stopped; o.rows_done = rows_done; o.overflow = ovf; o.besta = 0;
+    o.max_ext = max_ext; o.max_row = max_row; o.stopped = stopped; o.rows_done = rows_done; o.overflow = ovf; o.besta = pk_cols;
     o.pad = failed;
     *a.ctl_out = o;
   }

@@ -31,6 +31,7 @@ class RunInfo:
     persistent: int = 0
     lanes_per_flank: int = 1
     respeculated_rows: int = 0
+    packed_rows: int = 0
 
 
 def _params(p: ExtendParams):

@@ -201,6 +201,16 @@ def test_lean_band_switches_on_and_off_exactly(W, matrix, gap, short_frac, monke
         monkeypatch.delenv("RAMX_NO_LEAN")
         assert lean[0].persistent == 1 and lean[0].lanes_per_flank == 1
         runs = [lean]
+        # the packed row (prk_band_pk: two cells per register in relative int16, entered after a few in-bounds LEAN columns,
+        # left before the first column that is not one): really taken at the two-waves-per-SIMD widths, never with RAMX_NO_PK,
+        # and the rows it hands back (prk_unpack) are compared cell by cell below like every other run's
+        # (packed_rows counts the first wave's columns: with flanks that end early in it that wave may never qualify)
+        if short_frac == 0.0:
+            assert (lean[0].packed_rows > 100) == (W <= 40), (W, lean[0].packed_rows)
+        monkeypatch.setenv("RAMX_NO_PK", "1")
+        runs.append(_run_device(fs, p, 1, monkeypatch, True))
+        monkeypatch.delenv("RAMX_NO_PK")
+        assert runs[-1][0].packed_rows == 0 and full[0].packed_rows == 0
         # the leader path (prk_leader_rows: a wave with a few lanes that fail the LEAN test runs LEAN and computes those
         # lanes' candidate rows and best cell with all its lanes): off, and for any number of such lanes per wave
         for lm in ("0", "64"):
