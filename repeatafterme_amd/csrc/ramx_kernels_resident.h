@@ -527,7 +527,7 @@ __device__ __forceinline__ void prk_band(const int go, const int ge, const int *
 // register halves (v_max3_i16 / v_add_i16 with op_sel: the other half of the destination is kept); the chain register
 // C_k = (e[2k-1], e[2k]) is the third operand of the packed m = max(sub, Pe, C_k) and, stored as dword k of the lane's LDS
 // column (the d-row's slots), the deletion pair (e[2j+1], e[2j+2]) of pair j = k-1 in the next row.  A byte of the
-// phase-aligned base word is the class pair of two cells and indexes a 256-entry table of score pairs (one per winner,
+// phase-aligned base word is the class pair of two cells and indexes a 256-entry table of score pairs (one table per winner,
 // built once per launch).  641 instructions per row against ~1,100 for prk_band_fast<.., LEAN>.
 // Entered (prk_pack) after PRK_PK_AFTER consecutive in-bounds LEAN columns, left (prk_unpack) before the first column that is
 // not: the other bands never see this representation.
@@ -541,12 +541,25 @@ __device__ __forceinline__ int pk_max3_lll(int a, int b, int c) { int d; asm("v_
 __device__ __forceinline__ int pk_max3_hhh(int a, int b, int c) { int d; asm("v_max3_i16 %0, %1, %2, %3 op_sel:[1,1,1,0]" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
 __device__ __forceinline__ void pk_add_to_hi(int &dst, int a, int b) { asm("v_add_i16 %0, %1, %2 op_sel:[0,0,1]" : "+v"(dst) : "v"(a), "v"(b)); }
 __device__ __forceinline__ int pk_add_lo(int a, int b) { int d; asm("v_add_i16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+template <int BYTE>
+__device__ __forceinline__ unsigned pk_byte_x4(unsigned A)   // ((A >> 8*BYTE) & 0xff) << 2
+{
+  unsigned d;
+  if (BYTE == 0) asm("v_lshlrev_b32_sdwa %0, 2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(d) : "v"(A));
+  else if (BYTE == 1) asm("v_lshlrev_b32_sdwa %0, 2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(d) : "v"(A));
+  else if (BYTE == 2) asm("v_lshlrev_b32_sdwa %0, 2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(d) : "v"(A));
+  else asm("v_lshlrev_b32_sdwa %0, 2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(d) : "v"(A));
+  return d;
+}
 typedef short pk_s2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ pk_s2 pk_v(int x) { return __builtin_bit_cast(pk_s2, x); }
 __device__ __forceinline__ int pk_i(pk_s2 x) { return __builtin_bit_cast(int, x); }
 __device__ __forceinline__ int pk_two(int x) { return (x & 0xffff) | (x << 16); }
 
-struct PkTabs { int pair[256][4]; };   // [class pair][winner]: score of the low class | score of the high class << 16
+// [winner][class pair]: score of the low class | score of the high class << 16.  One table per winner, entries 4 bytes apart: the
+// pair index comes from two base codes, so interleaving the winners (16-byte stride) would put a wave's 64 lookups on the
+// nine banks its low codes select -- measured: 3.2 G bank-conflict cycles per launch and no gain from the packed row
+struct PkTabs { int pair[4][256]; };
 
 __device__ __forceinline__ void pk_tabs_init(PkTabs &pt, const int (&tab)[RAMX_NCLASS][4])
 {
@@ -555,7 +568,7 @@ __device__ __forceinline__ void pk_tabs_init(PkTabs &pt, const int (&tab)[RAMX_N
     const int lo = threadIdx.x & 15, hi = threadIdx.x >> 4;
 #pragma unroll
     for (int c = 0; c < 4; c++)
-      pt.pair[threadIdx.x][c] = ((lo < RAMX_NCLASS ? tab[lo][c] : 0) & 0xffff) | ((hi < RAMX_NCLASS ? tab[hi][c] : 0) << 16);
+      pt.pair[c][threadIdx.x] = ((lo < RAMX_NCLASS ? tab[lo][c] : 0) & 0xffff) | ((hi < RAMX_NCLASS ? tab[hi][c] : 0) << 16);
   }
 }
 
@@ -569,7 +582,7 @@ __device__ __forceinline__ int prk_band_pk(const int go, const int ge, const PkT
   const int go2 = pk_two(go), ge2 = pk_two(ge), neg2 = (int)0x80008000u;
   const int ph4 = 4 * ((r + 8) & 7);
   int *myE = sE + threadIdx.x;
-  const char *tb = reinterpret_cast<const char *>(&pt.pair[0][CSEL]);
+  const char *tb = reinterpret_cast<const char *>(&pt.pair[CSEL][0]);
   int C = neg2, best = neg2;            // C.lo = e of the cell before the pair
   unsigned A = 0;
   int tQ[PT], eQ[PT];
@@ -579,7 +592,7 @@ __device__ __forceinline__ int prk_band_pk(const int go, const int ge, const PkT
   {
     constexpr int k = decltype(kc)::value;
     if constexpr ((k & 3) == 0) A = __builtin_amdgcn_alignbit(w[(k >> 2) + 1], w[k >> 2], ph4);
-    return *reinterpret_cast<const int *>(tb + nib_lo_x16<(k & 3)>(A));
+    return *reinterpret_cast<const int *>(tb + pk_byte_x4<(k & 3)>(A));
   };
   static_for([&](auto kc) __attribute__((always_inline)) { tQ[decltype(kc)::value] = lookup(kc); }, std::make_integer_sequence<int, PT>{});
   static_for([&](auto kc) __attribute__((always_inline))
