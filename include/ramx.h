@@ -137,8 +137,9 @@ typedef struct ramx_run_info
   int32_t lanes_per_flank;  /* 1: one lane per flank; 2..16: the cell-parallel kernels split a band row over that many lanes */
   int32_t respeculated_rows; /* device-wide cell-parallel kernel: rows that workgroup 0 computed a second time because its own
                                guess of the vote was wrong (it runs ahead of the device-wide vote); 0 on every other route */
-  int32_t packed_rows;      /* lane-per-flank persistent kernel: columns that the first wave ran on the packed row (two cells per
-                               register, relative int16: in-bounds LEAN columns); 0 on every other route */
+  int32_t packed_rows;      /* columns that ran in the packed-row persistent kernel (two cells per register, int16 relative to a
+                               per-flank base: csrc/ramx_kernels_packed.h); 0 on every other route */
+  int32_t lean_rows;        /* ... of which the first wave ran as LEAN rows (no candidate rows, no best-cell index) */
 } ramx_run_info;
 
 int ramx_extend_flat(int direction, ramx_flat_cores *cores, const int8_t *sequence, uint64_t seq_len,

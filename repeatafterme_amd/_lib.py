@@ -42,7 +42,7 @@ class RunInfo(C.Structure):
                 ("overflow32", C.c_int32), ("n_extendable", C.c_int32), ("launches", C.c_int32),
                 ("loop_ms", C.c_double), ("kernel_ms_avg", C.c_double), ("kernel_samples", C.c_int32),
                 ("prep_ms", C.c_double), ("persistent", C.c_int32), ("lanes_per_flank", C.c_int32),
-                ("respeculated_rows", C.c_int32), ("packed_rows", C.c_int32)]
+                ("respeculated_rows", C.c_int32), ("packed_rows", C.c_int32), ("lean_rows", C.c_int32)]
 
 
 class Family(C.Structure):

@@ -49,6 +49,7 @@
 #include "ramx_kernels_stream.h"
 #include "ramx_kernels_resident.h"
 #include "ramx_cp_api.h"
+#include "ramx_pk_api.h"
 
 // ------------------------------------------------------------------------------------------
 // error plumbing
@@ -126,6 +127,8 @@ struct ramx_dev
   int *d_dbg_cand; int2 *d_dbg_gap; size_t cap_dbg_cand, cap_dbg_gap;
   CpDevDesc *d_devdesc; size_t cap_devdesc;       // device-wide cell-parallel launches: one descriptor per workgroup
   PShard *d_vote_sets; size_t cap_vote_sets; unsigned *d_err_sets; size_t cap_err_sets;   // batch mode: per-set vote / error words
+  int pk_r0;           // begin_direction: first row from which no flank has a low out-of-bounds cell (the packed-row kernel starts there); -1: none
+  int last_packed_r0;  // last direction: first row of the packed-row kernel, -1 if it did not run
   int cp_flanks_ok;    // begin_direction: every flank is empty or has t_lo <= 0 (what the cell-parallel kernels take)
   int2 *d_cpstate; size_t cap_cpstate; int cpstate_W, cpstate_n;   // RAMX_CP_PEEK=1: final rows of the cell-parallel kernel (tests)
 };
@@ -350,6 +353,12 @@ extern "C" int ramx_dev_begin_direction(ramx_dev *d, const ramx_flank *flanks, i
   d->cp_flanks_ok = 1;
   for (int i = 0; i < Nx; i++)
     if (flanks[i].t_lo > 0 && flanks[i].t_lo <= flanks[i].t_hi) { d->cp_flanks_ok = 0; break; }
+  // the packed-row kernel (ramx_kernels_packed.h) takes rows in which no flank has an out-of-bounds cell at the LOW end of the
+  // band: cell 0 of row r is flank position t = r - W, so a non-empty flank is clear from row t_lo + W on
+  d->pk_r0 = d->cp_flanks_ok ? 0 : -1;
+  if (d->cp_flanks_ok)
+    for (int i = 0; i < Nx; i++)
+      if (flanks[i].t_lo <= flanks[i].t_hi && flanks[i].t_lo + W > d->pk_r0) d->pk_r0 = flanks[i].t_lo + W;
   d->ready = 1;
   return RAMX_OK;
 }
@@ -687,7 +696,9 @@ static int prk_run(ramx_dev *d, const KArgs &a, int L, bool *used)
     if ((rc = host_allreduce_flag(d, &cannot)) != RAMX_OK) return rc;
     can = !cannot;
   }
-  if (!can) return RAMX_OK;
+  const bool int32_can = can;
+  const int pk_r0 = (getenv("RAMX_NO_PERSISTENT") != NULL || d->force_chain || L <= 0) ? -1 : d->pk_r0;
+  if (!can && (multi || pk_r0 < 0)) return RAMX_OK;
   *used = true;        // agreed (multi-rank: by all ranks): from here on the caller handles a local failure collectively
   PArgs pa;
   memset(&pa, 0, sizeof(pa));
@@ -740,43 +751,69 @@ static int prk_run(ramx_dev *d, const KArgs &a, int L, bool *used)
   pa.lean_p = lean_p_of(pa.tab, a.go, a.ge);
   // a leader costs its wave ~150 instructions in prk_leader_rows, the full band 640 more than LEAN; RAMX_LEADER_MAX=0 switches
   // the leader path off (A/B and tests), larger values exercise it on waves with many leaders
-  // packed LEAN rows (prk_band_pk): two cells per register in int16 relative to a per-flank base.  A cell lies at most
-  // max(PRK_PK_ENTER + 2W (|min| + |ge|) + |go|,  2W (P + |min| + |ge|) + |go| + |ge|) below its row's best cell, the base is at most
-  // PRK_PK_REBASE + 16 max(P, |min|) away from that, and sub + go / e need |go| + |ge| + P more: all of it must fit int16
-  pa.pk_ok = 0;
-  if (pa.lean_p >= 0 && pa.pack_ok && W <= 40 && getenv("RAMX_NO_PK") == NULL)
-  {
-    int mn = 0;
-    for (int c = 0; c < RAMX_NCLASS; c++)
-      for (int k = 0; k < 4; k++) if (pa.tab[c][k] < mn) mn = pa.tab[c][k];
-    const long long P = pa.lean_p, m = -(long long)mn, go_ = -(long long)a.go, ge_ = -(long long)a.ge;
-    const long long below = std::max(10000LL + 2LL * W * (m + ge_) + go_, 2LL * W * (P + m + ge_) + go_ + ge_);
-    const long long span = below + 8000LL + 16LL * std::max(P, m) + go_ + ge_ + P;
-    pa.pk_ok = span < 32000LL ? 1 : 0;
-  }
   { const char *lm = getenv("RAMX_LEADER_MAX"); pa.leader_max = lm ? atoi(lm) : 3; if (pa.leader_max < 0) pa.leader_max = 0; if (pa.leader_max > 64) pa.leader_max = 64; }
+  // ---- the packed-row kernel (ramx_kernels_packed.h) takes the direction from row r0 = d->pk_r0 on when the scoring system's
+  // rows fit int16 relative to a per-flank base; the rows before (flanks whose cores are shorter than the band have
+  // out-of-bounds cells at the LOW end of the band there) stay on this kernel, which hands over the sums of row r0 --------
+  PKArgs ka;
+  memset(&ka, 0, sizeof(ka));
+  int pk_block = 0, pk_blocks = 0;
+  bool pk = !multi && pk_r0 >= 0 && pk_r0 < L && ramx_pk_plan(W, a.go, a.ge, pa.tab, &ka.spread, &ka.rebase) != 0;
+  if (pk)
+  {
+    if ((rc = ramx_pk_shape(W, d->Np / 64, &pk_block, &pk_blocks)) != RAMX_OK) { ramx_set_error("packed-row kernel: occupancy query failed"); return RAMX_ERR_HIP; }
+    if (pk_block == 0 || (pk_r0 > 0 && !int32_can)) pk = false;
+  }
+  if (!pk && !int32_can) { *used = false; return RAMX_OK; }
   HIPCHK(hipMemsetAsync(d->d_vote, 0, PRK_NSETS * NSHARD * sizeof(PShard), d->stream));
   HIPCHK(hipMemsetAsync(d->d_err, 0, 64, d->stream));
+  long long *sums_next = d->d_sums + (size_t)NSHARD * 4;        // slot 1: zeroed by K(-1)
+  const bool head = !pk || pk_r0 > 0;                            // this kernel runs (all of the direction, or its first rows)
+  if (pk && pk_r0 > 0) { pa.L = pk_r0; pa.sums_next = sums_next; }
 #ifdef RAMX_PRK_TIMING
-  const size_t nw = (size_t)blocks * (block / 64);
-  HIPCHK(hipMalloc((void **)&pa.dbg, nw * 8 * sizeof(unsigned long long)));
-  HIPCHK(hipMemset(pa.dbg, 0, nw * 8 * sizeof(unsigned long long)));
+  const size_t nw = pk ? (size_t)pk_blocks * (pk_block / 64) : (size_t)blocks * (block / 64);
+  unsigned long long *dbgbuf = NULL;
+  HIPCHK(hipMalloc((void **)&dbgbuf, nw * 8 * sizeof(unsigned long long)));
+  HIPCHK(hipMemset(dbgbuf, 0, nw * 8 * sizeof(unsigned long long)));
+  if (pk) ka.dbg = dbgbuf; else pa.dbg = dbgbuf;                 // timing build: with a packed launch, its phases are the ones printed
 #endif
-  if (block == 256)
-    rc = (W == 14) ? prk_launch<14, 256>(d, pa, blocks) : (W == 20) ? prk_launch<20, 256>(d, pa, blocks) :
-         (W == 40) ? prk_launch<40, 256>(d, pa, blocks) : prk_launch<80, 256>(d, pa, blocks);
-  else
-    rc = (W == 14) ? prk_launch<14, 512>(d, pa, blocks) : (W == 20) ? prk_launch<20, 512>(d, pa, blocks) : prk_launch<40, 512>(d, pa, blocks);
+  rc = RAMX_OK;
+  if (head)
+  {
+    if (block == 256)
+      rc = (W == 14) ? prk_launch<14, 256>(d, pa, blocks) : (W == 20) ? prk_launch<20, 256>(d, pa, blocks) :
+           (W == 40) ? prk_launch<40, 256>(d, pa, blocks) : prk_launch<80, 256>(d, pa, blocks);
+    else
+      rc = (W == 14) ? prk_launch<14, 512>(d, pa, blocks) : (W == 20) ? prk_launch<20, 512>(d, pa, blocks) : prk_launch<40, 512>(d, pa, blocks);
+  }
+  if (rc == RAMX_OK && pk)
+  {
+    if (head) HIPCHK(hipMemsetAsync(d->d_vote, 0, PRK_NSETS * NSHARD * sizeof(PShard), d->stream));
+    ka.S = d->d_state[0]; ka.bases = d->d_bases; ka.bounds = d->d_bounds; ka.trim = d->d_trim;
+    ka.sums_in = pk_r0 > 0 ? sums_next : d->d_sums; ka.vote = d->d_vote;
+    ka.ctl_in = d->d_ctl; ka.ctl_out = pk_r0 > 0 ? d->d_ctl + 1 : d->d_ctl;      // the first launch's block goes in, the final one out
+    ka.cons_out = d->d_cons; ka.err = d->d_err;
+    ka.peers = NULL; ka.box = NULL; ka.mirror = NULL; ka.rank = 0; ka.nranks = 1;
+    ka.Np = d->Np; ka.Nx = d->Nx; ka.r0 = pk_r0; ka.L = L; ka.go = a.go; ka.ge = a.ge; ka.cap = a.cap; ka.minimp = a.minimp;
+    ka.when_to_stop = a.when_to_stop; ka.nblocks = pk_blocks;
+    memcpy(ka.tab, a.tab, sizeof(ka.tab));
+    ka.lean_p = pa.lean_p; ka.leader_max = pa.leader_max;
+    rc = ramx_pk_launch(d->stream, W, pk_block, pk_blocks, ka);
+    if (rc != RAMX_OK) ramx_set_error("packed-row kernel: launch failed (W %d, %d workgroups of %d threads)", W, pk_blocks, pk_block);
+    d->last_packed_r0 = pk_r0;
+    if (pk) { block = pk_block; blocks = pk_blocks; }
+  }
+  else d->last_packed_r0 = -1;
 #ifdef RAMX_PRK_TIMING
   if (rc == RAMX_OK)
   {
     // debug build: phase breakdown per column, in ns (wall_clock64 ticks are 10 ns)
     HIPCHK(hipStreamSynchronize(d->stream));
     unsigned long long *h = (unsigned long long *)malloc(nw * 8 * sizeof(unsigned long long));
-    HIPCHK(hipMemcpy(h, pa.dbg, nw * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    static const char *nm[6] = { "wait vote", "block barrier 1", "band", "reduce+barrier 2", "issue atomics", "loop top" };
+    HIPCHK(hipMemcpy(h, dbgbuf, nw * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    static const char *nm[6] = { "wait vote", "block barrier 1", "band", pk ? "early arrival" : "reduce+barrier 2", pk ? "late arrival" : "issue atomics", "loop top" };
     const int wpb = block / 64;
-    fprintf(stderr, "PRK_TIMING blocks %d x %d threads, L %d (ns per column)\n", blocks, block, L);
+    fprintf(stderr, "PRK_TIMING %s blocks %d x %d threads, L %d, first row %d (ns per column)\n", pk ? "packed rows" : "int32 rows", blocks, block, L, pk ? pk_r0 : 0);
     for (int k = 0; k < 6; k++)
     {
       double s0 = 0, sO = 0, mx = 0, mn = 1e30;
@@ -825,7 +862,7 @@ static int prk_run(ramx_dev *d, const KArgs &a, int L, bool *used)
               half, never, nw, always, wg_any, blocks, cols > 0 ? lanes / cols : 0.0, hist[0], hist[1], hist[2], hist[3], hist[4], hist[5]);
     }
     free(h);
-    (void)hipFree(pa.dbg);
+    (void)hipFree(dbgbuf);
   }
 #endif
   return rc;
@@ -1553,10 +1590,16 @@ extern "C" int ramx_dev_run_direction(ramx_dev *d, ramx_run_info *info)
     // single GPU: a barrier that timed out (bounded spin, e.g. a co-tenant holding CUs) is not fatal -- repeat the
     // direction with the per-column launches, exactly as the multi-rank branch above does
     HIPCHK(hipStreamSynchronize(d->stream));
-    RamxCtl c0;
-    HIPCHK(hipMemcpy(&c0, d->d_ctl, sizeof(c0), hipMemcpyDeviceToHost));
-    if (c0.pad != 0)
+    RamxCtl c0[2];
+    unsigned errw = 0;
+    HIPCHK(hipMemcpy(c0, d->d_ctl, sizeof(c0), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&errw, d->d_err, sizeof(errw), hipMemcpyDeviceToHost));
+    if (c0[0].pad != 0 || (d->last_packed_r0 > 0 && c0[1].pad != 0) || errw != 0)
     {
+      if (errw == 2)
+        fprintf(stderr, "ramx: the packed-row kernel refused the rows (a cell outside the span computed for this scoring system); repeating "
+                        "the direction with per-column launches\n");
+      else
       fprintf(stderr, "ramx: device-wide barrier of the persistent launch timed out (bounded spin); repeating the direction with "
                       "per-column launches\n");
       persistent = false;
@@ -1655,7 +1698,8 @@ extern "C" int ramx_dev_run_direction(ramx_dev *d, ramx_run_info *info)
     info->persistent = persistent ? 1 : 0;
     info->lanes_per_flank = lanes;
     info->respeculated_rows = cp_done ? f.besta : 0;
-    info->packed_rows = (persistent && !cp_done) ? f.besta : 0;
+    info->packed_rows = (persistent && !cp_done && d->last_packed_r0 >= 0 && f.rows_done > d->last_packed_r0) ? f.rows_done - d->last_packed_r0 : 0;
+    info->lean_rows = (persistent && !cp_done && d->last_packed_r0 >= 0) ? f.besta : 0;
   }
   return RAMX_OK;
 }

@@ -1,0 +1,640 @@
+// ramx_kernels_packed.h -- the lane-per-flank persistent kernel on PACKED rows: two cells of a flank's row per register, int16
+// relative to a per-flank 32-bit base (device code of libramx; included by ramx_packed.hip only).
+//
+// What is computed is the reference's column step (ram_extend.c:970-1223 around compute_nw_row, bnw_extend.c:750-1048) exactly
+// as in ramx_kernels_resident.h -- one lane = one flank for the whole direction, the device-wide vote of ramx_kernels_vote.h --
+// on another representation of the row:
+//
+//   R[k] = (m[2k], m[2k+1])        m = max(sub, gap) of a cell                                          k = 0 .. W
+//   E[k] = (e[2k-1], e[2k])        e = max(sub + go, gap) + ge: the cell's value as a gap predecessor
+//
+// both as int16 relative to the lane's `pbase`, both in VECTOR REGISTERS (2 (W + 1) of them: 82 at W = 40 where the int32 row
+// needed 81 registers plus 162 bytes of LDS per lane, and 162 at W = 80, which therefore runs two waves per SIMD as well).
+// Why the values fit: an in-bounds cell of row r lies at most 3W (P + |min score| + |ge|) + |go| + W |ge| below the row's best
+// cell (take the best path into the row's best cell, leave it 2W rows earlier, and walk to the cell with substitutions and ONE
+// gap: every step of the detour is in bounds because sequence positions only grow along a path and the target is in bounds;
+// rows below 3W are bounded absolutely), the best cell moves by at most max(P, |min score|) per row, and the base follows it
+// every 16th row once it is more than `rebase` away.  The host admits a scoring system only if all of it fits int16 with the
+// intermediates (ramx_pk_plan), and the entry check below refuses rows that do not (the direction then runs on the int32 rows).
+//
+// Per pair of cells (bnw_extend.c:892-1018 on the transformed state, see ramx_kernels_common.h):
+//   sub  = R[k] + S                        two cells per instruction (v_pk_add_i16; S: score pair of the pair's two base classes,
+//   sg   = sub + go                        one LDS read of a 256-entry table indexed by a byte of the phase-aligned base word)
+//   t    = max3(sg.lo, E'[k+1].lo, C.lo)   cell 2k:   max(sub + go, deletion, insertion)            (E': previous row)
+//   C.hi = t + ge                          e[2k]                                                      (C = (e[2k-1], e[2k]))
+//   R[k] = max(sub, E'[k+1], C)            both cells
+//   E[k] = C
+//   t2   = max3(sg.hi, E'[k+1].hi, C.hi)   cell 2k+1
+//   C'.lo = t2 + ge                        e[2k+1]: the next pair's chain register
+// The insertion chain runs a cell at a time on register halves (v_max3_i16 / v_add_i16 with op_sel), everything else two cells
+// per instruction.  FULL rows add the four candidate rows r+1 (chain-free, ramx_kernels_common.h: 4 packed adds + 4 packed maxima
+// per pair on (m[2k-1], m[2k]), their common deletion term max e folded in at the end) and the best cell's index (keys
+// (m << 16 | 31 - cell % 32), three groups of 32 cells at W = 40); LEAN rows (no lane can contribute more than its cap or set a
+// record, ramx_kernels_resident.h) only the row and its best value.
+//
+// Far end of a flank.  Cells beyond the flank's last base (j > jhi) hold the sentinel in the reference (bnw_extend.c:990-1002).
+// Here they need no masked variant of the band: base-word nibbles beyond the flank's end are replaced ONCE, when a word is
+// loaded (every eighth column), by class 15, whose scores are -32768 in every table, and every addition saturates.  Then
+//   * an out-of-bounds cell's substitution term is pinned far below every in-bounds value;
+//   * in-bounds cells never read out-of-bounds ones (cell j of row r reads cells j, j+1 of row r-1 and cell j-1 of row r; the
+//     in-bounds cells of a row are 0 .. jhi(r) and jhi(r-1) = jhi(r) + 1);
+//   * what an out-of-bounds cell does take is the insertion chain out of cell jhi and deletions out of out-of-bounds cells of
+//     the row before, and by induction m[j] <= m[jhi] + ge and e[j] <= e[jhi] + ge for j > jhi: such a cell never holds the
+//     row's best (ties go to the lower cell), its e never raises the candidates' deletion term, and its candidate terms are
+//     pinned by class 15 again.
+// Lanes whose flank has run out completely (jhi < 0: best cell = sentinel) and lanes without a valid candidate cell (jhi < 1)
+// are patched after the band, per lane.  The rows written back at the end carry the reference's fill values in those cells.
+// What this kernel does NOT take is a row whose LOW cells are out of bounds (the first rows of a flank whose core is shorter
+// than the band: their fill value go + (row+1) ge feeds in-bounds neighbours): the host starts it at the first row r0 from
+// which every flank has jlo <= 0 and runs the rows before on the int32 kernel (ramx_pk_first_row).
+//
+// The vote.  One workgroup barrier per column (the vote wave publishes, everybody reads) and an LDS arrival counter instead of
+// the second one: a wave adds its four sums to the workgroup's totals when it has them, the LAST arriver sends the ticket.  A
+// LEAN wave without leaders has its sums BEFORE the band (its contribution is the sum of its caps, ram_extend.c:1052-1062), so
+// an all-LEAN workgroup's ticket leaves at the start of the column and the exchange runs beside the band instead of behind it;
+// a workgroup that holds a leader or a FULL wave sends when that wave is done -- the other seven do not wait for it.
+#pragma once
+
+#include "ramx_kernels_vote.h"
+#include "ramx_pk_api.h"
+
+template <int W>
+struct PkCfg
+{
+  static constexpr int B = 2 * W + 1, NP = W + 1, NW = (B + 8) / 8 + 2, NG = (B + 31) / 32, Q = W + 1;
+};
+
+#define PKB_NEG2 ((int)0x80008000u)
+
+__device__ __forceinline__ int pkb_add_sat(int a, int b) { int d; asm("v_pk_add_i16 %0, %1, %2 clamp" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ int pkb_sub_sat(int a, int b) { int d; asm("v_pk_sub_i16 %0, %1, %2 clamp" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ int pkb_max(int a, int b) { return pk_i(__builtin_elementwise_max(pk_v(a), pk_v(b))); }
+// dst.hi = sat(a.lo + b.lo), dst.lo kept
+__device__ __forceinline__ void pkb_add_to_hi(int &dst, int a, int b) { asm("v_add_i16 %0, %1, %2 op_sel:[0,0,1] clamp" : "+v"(dst) : "v"(a), "v"(b)); }
+// d.lo = sat(a.lo + b.lo) (d.hi: whatever the register held)
+__device__ __forceinline__ int pkb_add_lo(int a, int b) { int d; asm("v_add_i16 %0, %1, %2 clamp" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ int pkb_hmax(int p) { const pk_s2 q = pk_v(p); return q.x > q.y ? (int)q.x : (int)q.y; }
+__device__ __forceinline__ unsigned pkb_lds_off(const void *p) { return (unsigned)(size_t)(__attribute__((address_space(3))) const void *)p; }
+
+// nibbles of base word `kb` (absolute index) beyond the flank's last base become class 15: nibble i of word kb is flank position
+// t'' = 8 kb + i, out of bounds iff t'' > bdy + 8
+__device__ __forceinline__ unsigned pkb_mask_word(unsigned wv, int kb, int bdy9x4 /* 4 (bdy + 9) */)
+{
+  int s = bdy9x4 - 32 * kb;                        // 4 x (number of in-bounds nibbles of this word), unclamped
+  s = s < 0 ? 0 : s;
+  const unsigned m = s >= 32 ? 0u : (0xffffffffu << s);
+  return wv | m;
+}
+
+struct PkTabs
+{
+  int4 t4[256];           // [class pair byte]: the four candidates' score pairs (low class | high class << 16): FULL rows
+  int tp[4][256];         // [winner][class pair byte]: LEAN rows (entries 4 bytes apart: see ramx_kernels_resident.h)
+};
+
+template <int BLOCK>
+__device__ __forceinline__ void pkb_tabs_init(PkTabs &pt, const int (&tab)[RAMX_NCLASS][4])
+{
+  for (int i = threadIdx.x; i < 256; i += BLOCK)
+  {
+    const int lo = i & 15, hi = i >> 4;
+    int q[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+    {
+      const int sl = lo < RAMX_NCLASS ? tab[lo][c] : (lo == 15 ? -32768 : 0);
+      const int sh = hi < RAMX_NCLASS ? tab[hi][c] : (hi == 15 ? -32768 : 0);
+      q[c] = (sl & 0xffff) | (sh << 16);
+      pt.tp[c][i] = q[c];
+    }
+    pt.t4[i] = make_int4(q[0], q[1], q[2], q[3]);
+  }
+}
+
+// One row on the packed representation.  CSEL: the winner (compile time: its dword of a table row is a register of the loaded
+// quad / its table's address is part of the instruction's offset).  ph4: 4 x the nibble phase of step 0 in w[0].
+// FULL: kg[] = best cell keys per group of 32 cells, bA[] = the candidates' running maxima (packed), maxE = max e (packed);
+// LEAN: best = the row's best value (packed halves).
+template <int W, int BLOCK, int CSEL, bool FULL>
+__device__ __forceinline__ void pkb_band(const int go2, const int ge2, const PkTabs &pt, const int ph4, const unsigned (&w)[PkCfg<W>::NW],
+                                         int (&R)[PkCfg<W>::NP], int (&E)[PkCfg<W>::NP], int &best, int (&kg)[PkCfg<W>::NG], int (&bA)[4], int &maxE)
+{
+  constexpr int B = PkCfg<W>::B, NP = PkCfg<W>::NP, NG = PkCfg<W>::NG, PT = 2;
+  const char *tb = FULL ? reinterpret_cast<const char *>(&pt.t4[0]) : reinterpret_cast<const char *>(&pt.tp[CSEL][0]);
+  const int hmask = (int)0xffff0000u;
+  int C = PKB_NEG2, Rprev = PKB_NEG2;
+  best = PKB_NEG2; maxE = PKB_NEG2;
+#pragma unroll
+  for (int c = 0; c < 4; c++) bA[c] = PKB_NEG2;
+#pragma unroll
+  for (int g = 0; g < NG; g++) kg[g] = -2147483647 - 1;
+  unsigned A = 0;
+  int tQ[PT];
+  int cQ[FULL ? PT : 1][4];
+  auto lookup = [&](auto kc, auto qc) __attribute__((always_inline))
+  {
+    constexpr int k = decltype(kc)::value, qi = decltype(qc)::value;
+    if constexpr ((k & 3) == 0) A = __builtin_amdgcn_alignbit(w[(k >> 2) + 1], w[k >> 2], ph4);
+    if constexpr (FULL)
+    {
+      const int4 v4 = *reinterpret_cast<const int4 *>(tb + pk_byte_shl<(k & 3), 4>(A));
+      cQ[qi][0] = v4.x; cQ[qi][1] = v4.y; cQ[qi][2] = v4.z; cQ[qi][3] = v4.w;
+      tQ[qi] = CSEL == 0 ? v4.x : CSEL == 1 ? v4.y : CSEL == 2 ? v4.z : v4.w;
+    }
+    else tQ[qi] = *reinterpret_cast<const int *>(tb + pk_byte_shl<(k & 3), 2>(A));
+  };
+  static_for([&](auto kc) __attribute__((always_inline)) { lookup(kc, kc); }, std::make_integer_sequence<int, PT>{});
+  static_for([&](auto kc) __attribute__((always_inline))
+  {
+    constexpr int k = decltype(kc)::value;
+    if constexpr ((k & 1) == 0)
+    {
+      // pin the accumulators to their group (a sunk accumulation keeps every table row alive, as in prk_band_fast)
+      if constexpr (FULL) asm volatile("" ::"v"(C), "v"(bA[0]), "v"(bA[1]), "v"(bA[2]), "v"(bA[3]), "v"(maxE), "v"(kg[(k > 0 ? 2 * k - 1 : 0) >> 5]));
+      else asm volatile("" ::"v"(best), "v"(C));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    const int S = tQ[0];
+    int sc[4] = { 0, 0, 0, 0 };
+    if constexpr (FULL) { sc[0] = cQ[0][0]; sc[1] = cQ[0][1]; sc[2] = cQ[0][2]; sc[3] = cQ[0][3]; }
+#pragma unroll
+    for (int q = 0; q + 1 < PT; q++)
+    {
+      tQ[q] = tQ[q + 1];
+      if constexpr (FULL) { cQ[q][0] = cQ[q + 1][0]; cQ[q][1] = cQ[q + 1][1]; cQ[q][2] = cQ[q + 1][2]; cQ[q][3] = cQ[q + 1][3]; }
+    }
+    if constexpr (k + PT < NP) lookup(std::integral_constant<int, (k + PT < NP ? k + PT : 0)>{}, std::integral_constant<int, PT - 1>{});
+    const int PeP = k + 1 < NP ? E[k + 1 < NP ? k + 1 : 0] : PKB_NEG2;        // (e'[2k+1], e'[2k+2]): cell 2W has no deletion (bnw_extend.c:892)
+    const int sub = pkb_add_sat(R[k], S);                       // bnw_extend.c:950-956, two cells
+    const int sg = pkb_add_sat(sub, go2);
+    const int t = pk_max3_lll(sg, PeP, C);                      // cell 2k: max(sub + go, del, ins), :1007-1018
+    pkb_add_to_hi(C, t, ge2);                                   // C = (e[2k-1], e[2k])
+    int m = pkb_max(pkb_max(sub, PeP), C);
+    E[k] = C;
+    if constexpr (FULL) { if constexpr (k > 0) maxE = pkb_max(maxE, C); }     // deletion terms of candidate cells 2k-2, 2k-1 (e[0] is nobody's)
+    if constexpr (2 * k + 1 < B)
+    {
+      const int t2 = pk_max3_hhh(sg, PeP, C);                   // cell 2k+1
+      C = pkb_add_lo(t2, ge2);                                  // the next pair's chain register: lo = e[2k+1]
+    }
+    else m = (m & 0xffff) | (int)0x80000000u;                   // there is no cell 2W+1
+    R[k] = m;
+    if constexpr (FULL)
+    {
+      // best cell of the row: keys (value << 16 | 31 - cell % 32), the lowest cell wins ties (bnw_extend.c:1020-1024)
+      constexpr int g = (2 * k) >> 5;
+      const int klo = (int)(((unsigned)m << 16) | (unsigned)(31 - ((2 * k) & 31)));
+      if constexpr (2 * k + 1 < B)
+      {
+        const int khi = (m & hmask) | (31 - ((2 * k + 1) & 31));
+        kg[g] = imax3(kg[g], klo, khi);
+      }
+      else kg[g] = imax(kg[g], klo);
+      // candidate cells 2k-1 and 2k of row r+1: substitution from (m[2k-1], m[2k]) with the classes of steps 2k, 2k+1
+      const int ms = (int)__builtin_amdgcn_alignbit((unsigned)m, (unsigned)Rprev, 16);      // k = 0: (-32768, m[0]): there is no cell -1
+#pragma unroll
+      for (int c = 0; c < 4; c++) bA[c] = pkb_max(bA[c], pkb_add_sat(ms, sc[c]));
+      Rprev = m;
+    }
+    else best = pkb_max(best, m);
+  }, std::make_integer_sequence<int, NP>{});
+}
+
+// Leaders (ramx_kernels_resident.h, prk_leader_rows): what a LEAN row skipped, for ONE flank of the wave, by all 64 lanes.  The
+// leader's lane publishes its new row, its chain registers and its base words; lane i takes cells i, i + 64, ..: candidate cell k
+// of row r+1 = m_k + M[a][class of step k+1], deletion terms e_k, five wave maxima, the lowest cell holding the row's best.
+template <int W, int BLOCK>
+__device__ __forceinline__ void pkb_leader_rows(const PkTabs &pt, int *scr /* [2 NP + NW] of this wave */, const int ph, const int leader,
+                                                const int pbase, const int jhi, const int bestF,
+                                                const unsigned (&w)[PkCfg<W>::NW], const int (&R)[PkCfg<W>::NP], const int (&E)[PkCfg<W>::NP],
+                                                int (&bestA)[4], int &jbest)
+{
+  constexpr int B = PkCfg<W>::B, NW = PkCfg<W>::NW, NP = PkCfg<W>::NP;
+  constexpr int NH = (B + 63) / 64;
+  const int lane = threadIdx.x & 63;
+  if (lane == leader)
+  {
+    static_for([&](auto kc) __attribute__((always_inline)) { constexpr int k = decltype(kc)::value; scr[k] = R[k]; scr[NP + k] = E[k]; },
+               std::make_integer_sequence<int, NP>{});
+    static_for([&](auto kc) __attribute__((always_inline)) { constexpr int k = decltype(kc)::value; scr[2 * NP + k] = (int)w[k]; },
+               std::make_integer_sequence<int, NW>{});
+  }
+  __builtin_amdgcn_wave_barrier();          // LDS operations of a wave execute in order; this only pins the compiler's order
+  const int bf = __builtin_amdgcn_readlane(bestF, leader);
+  const int lbase = __builtin_amdgcn_readlane(pbase, leader);
+  const int ljhi = __builtin_amdgcn_readlane(jhi, leader);
+  int ta[4] = { NEG, NEG, NEG, NEG }, me = NEG;
+  unsigned long long hit[NH];
+#pragma unroll
+  for (int h = 0; h < NH; h++)
+  {
+    const int k = lane + 64 * h;
+    const bool ok = k < B && k <= ljhi;                 // cell k of row r in bounds
+    const int kk = k < B ? k : 0;
+    const int mw = scr[kk >> 1];
+    const int m = lbase + ((kk & 1) ? (mw >> 16) : (int)(short)mw);
+    const int g = kk + 1 + ph;                           // nibble of step k+1 in the base words
+    const unsigned cls = ((unsigned)scr[2 * NP + (g >> 3)] >> (4 * (g & 7))) & 15u;
+    if (ok && k + 1 <= ljhi)                             // candidate cell k of row r+1 in bounds (bounds move by one per row)
+    {
+#pragma unroll
+      for (int c = 0; c < 4; c++) ta[c] = imax(ta[c], m + (int)(short)pt.tp[c][cls]);
+    }
+    if (ok && k >= 1)
+    {
+      const int cw = scr[NP + ((kk + 1) >> 1)];          // E[(k+1)/2] = (e[k] | .) for odd k, (. | e[k]) for even k
+      me = imax(me, lbase + ((kk & 1) ? (int)(short)cw : (cw >> 16)));
+    }
+    hit[h] = __ballot(ok && m == bf);
+  }
+  const int mx = wave_max_i32_dpp(me);
+  int best[4];
+#pragma unroll
+  for (int c = 0; c < 4; c++) best[c] = imax(wave_max_i32_dpp(ta[c]), mx);
+  int jb = 0;                                            // lowest cell on ties (bnw_extend.c:1020-1024)
+#pragma unroll
+  for (int h = NH - 1; h >= 0; h--)
+    if (hit[h]) jb = 64 * h + __builtin_ctzll(hit[h]);
+  if (lane == leader)
+  {
+#pragma unroll
+    for (int c = 0; c < 4; c++) bestA[c] = best[c];
+    jbest = jb;
+  }
+}
+
+#ifdef RAMX_PRK_TIMING
+#define PKB_TICK(k) do { const unsigned long long t_ = wall_clock64(); tsum[k] += t_ - tlast; tlast = t_; } while (0)
+#else
+#define PKB_TICK(k) do { } while (0)
+#endif
+
+template <int W, int BLOCK>
+__global__ __launch_bounds__(BLOCK, BLOCK / 256) void ramx_packed_kernel(const PKArgs a)
+{
+  constexpr int B = PkCfg<W>::B, NP = PkCfg<W>::NP, NW = PkCfg<W>::NW, NG = PkCfg<W>::NG, Q = PkCfg<W>::Q, WPB = BLOCK / 64;
+  struct Smem      // tables first: their LDS addresses must fit the 16-bit offset field of the ds_read that uses them
+  {
+    PkTabs pt;
+    long long tot[2][4];                               // the workgroup's four sums of the next row, by column parity
+    long long vote[2][4];                              // by column parity: a straggler may still read row r's while the vote wave writes row r+1's
+    int cnt[2];                                        // waves that have added theirs
+    int fail[2];
+    int lead[WPB][2 * NP + NW + 1];                    // pkb_leader_rows: a leader's row, chain registers and base words, per wave
+  };
+  __shared__ __attribute__((aligned(16))) Smem sm;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tile = blockIdx.x * WPB + wave;
+  const bool live = tile < (a.Np >> 6);
+  const int n = (live ? tile : 0) * 64 + lane;
+  int4 *S = a.S + (size_t)(live ? tile : 0) * Q * 64 + lane;
+  const int2 bd = a.bounds[n];
+  // last in-bounds band cell of row r: jhi = bdy - r.  Padding lanes (no flank: an all-N base stream, their vote is masked) are
+  // never clipped; an empty flank has no in-bounds cell in any row
+  const int bdy = (n >= a.Nx) ? 0x3fffffff : (bd.x > bd.y ? -0x40000000 : bd.y);
+  const int bdy9x4 = bdy > 0x07ffffff ? 0x3fffffff : (bdy < -0x08000000 ? -0x40000000 : 4 * (bdy + 9));
+  const int shard = blockIdx.x % NSHARD;
+  const int my_shard_blocks = (a.nblocks - (lane & (NSHARD - 1)) + NSHARD - 1) / NSHARD;   // wave 0: blocks arriving on shard `lane & 31`
+  const int go2 = pk_two(a.go), ge2 = pk_two(a.ge);
+
+  pkb_tabs_init<BLOCK>(sm.pt, a.tab);
+  if (threadIdx.x < 8) (&sm.tot[0][0])[threadIdx.x] = 0;
+  if (threadIdx.x < 2) sm.cnt[threadIdx.x] = 0;
+  if (threadIdx.x < 2) sm.fail[threadIdx.x] = 0;
+
+  // ---- stop-rule state and records so far -------------------------------------------------------
+  long long max_ext = 0;
+  int max_row = -1, rows_done = a.r0, ovf = 0, stopped = 0, failed = 0;
+  int thigh = 0, tpos = 0;
+  if (a.r0 > 0)
+  {
+    const RamxCtl ci = *a.ctl_in;
+    max_ext = ci.max_ext; max_row = ci.max_row; rows_done = ci.rows_done; ovf = ci.overflow;
+    stopped = ci.stopped || ci.rows_done < a.r0;       // the launch before this one stopped (or gave up) early
+    failed = ci.pad;
+    const int2 t = a.trim[n];
+    thigh = t.x; tpos = t.y;
+  }
+  const bool skip = stopped || failed || a.r0 >= a.L;
+
+  // ---- row state -> packed registers -----------------------------------------------------------
+  int R[NP], E[NP];
+  int high, pos, pbase = 0;
+  {
+    // cells above jcut (beyond the flank's end in row r0 - 1) are never read by an in-bounds cell of a later row: pinned at once
+    const int jcut = bdy - (a.r0 - 1);
+    int bmax = -2147483647 - 1, bmin = 2147483647;
+    // each pass over the row walks its own opaque copy of the pointer: 41 slot addresses shared between the two passes here and
+    // the write-back at the end would stay alive through the whole kernel (82 registers)
+    const int4 *S1 = S;
+    asm volatile("" : "+v"(S1));
+    // (every access to R / E / w is through compile-time indices: an array indexed by an unrolled loop variable is turned into
+    // one wide vector register by the alloca promotion that runs before unrolling, and every branch then copies it whole)
+    static_for([&](auto qc) __attribute__((always_inline))
+    {
+      constexpr int q = decltype(qc)::value;
+      // a few slots in flight at a time: the whole row in flight would be the register peak of the kernel
+      if constexpr ((q & 7) == 0) __builtin_amdgcn_sched_barrier(0);
+      const int4 v = S1[(size_t)q * 64];
+      const int x0 = 2 * q <= jcut ? v.x : -2147483647 - 1, n0 = 2 * q <= jcut ? v.x : 2147483647;
+      bmax = imax(bmax, x0); bmin = n0 < bmin ? n0 : bmin;
+      if constexpr (q < W)
+      {
+        const int x1 = 2 * q + 1 <= jcut ? v.z : -2147483647 - 1, n1 = 2 * q + 1 <= jcut ? v.z : 2147483647;
+        bmax = imax(bmax, x1); bmin = n1 < bmin ? n1 : bmin;
+      }
+    }, std::make_integer_sequence<int, Q>{});
+    __builtin_amdgcn_sched_barrier(0);
+    const bool none = bmax == -2147483647 - 1;
+    pbase = none ? 0 : bmax;
+    // entry check: every in-bounds cell within the span the host computed (else this representation is not safe: give up loudly)
+    if (live && !skip && n < a.Nx && !none && (long long)bmax - (long long)bmin > (long long)a.spread)
+      __hip_atomic_store(a.err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int jcut2 = jcut;
+    const int4 *S2 = S;
+    asm volatile("" : "+v"(jcut2), "+v"(S2));                     // second pass: its own comparisons (the first pass's would be kept in scalar registers)
+    auto rel16 = [&](int x, bool inb) __attribute__((always_inline)) -> int
+    {
+      int d = x - pbase;                                // in-bounds cells: within `spread` of the base; others are pinned below
+      d = d < -32768 ? -32768 : (d > 32767 ? 32767 : d);
+      return inb ? d : -32768;
+    };
+    int eprev = -32768;                                 // e[2k-1] relative
+    static_for([&](auto qc) __attribute__((always_inline))
+    {
+      constexpr int q = decltype(qc)::value;
+      if constexpr ((q & 7) == 0) __builtin_amdgcn_sched_barrier(0);
+      const int4 v = S2[(size_t)q * 64];
+      const bool in0 = 2 * q <= jcut2, in1 = q < W && 2 * q + 1 <= jcut2;
+      const int m0 = rel16(v.x, in0), e0 = rel16(v.y, in0);
+      const int m1 = q < W ? rel16(v.z, in1) : -32768, e1 = q < W ? rel16(v.w, in1) : -32768;
+      R[q] = (m0 & 0xffff) | (m1 << 16);
+      E[q] = (eprev & 0xffff) | (e0 << 16);
+      eprev = e1;
+      if constexpr (q == W) { high = v.z; pos = v.w; }
+    }, std::make_integer_sequence<int, Q>{});
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (skip)
+  {
+    // nothing to do: the control block passes through unchanged (the rows in HBM are the ones of the launch before)
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+    {
+      RamxCtl o;
+      o.max_ext = max_ext; o.max_row = max_row; o.stopped = stopped; o.rows_done = rows_done; o.overflow = ovf; o.besta = 0; o.pad = failed;
+      *a.ctl_out = o;
+    }
+    return;
+  }
+
+  // ---- base words: carried across columns, one new word every eighth column, far-end nibbles masked when a word comes in ----
+  unsigned w[NW], wnext;
+  {
+    const int k0 = (a.r0 + 8) >> 3;
+    const unsigned *bp = a.bases + (size_t)k0 * a.Np + n;
+    static_for([&](auto kc) __attribute__((always_inline)) { constexpr int k = decltype(kc)::value; w[k] = pkb_mask_word(bp[(size_t)k * a.Np], k0 + k, bdy9x4); },
+               std::make_integer_sequence<int, NW>{});
+    wnext = pkb_mask_word(bp[(size_t)NW * a.Np], k0 + NW, bdy9x4);
+  }
+  __syncthreads();
+
+  int prevBest = 0x3fffffff;             // best cell of the previous row (LEAN test): unknown before the first band of this launch
+  int full_rows = 0, lean_rows = 0;      // wave 0 of workgroup 0: rows by variant (reported)
+#ifdef RAMX_PRK_TIMING
+  unsigned long long tsum[6] = { 0, 0, 0, 0, 0, 0 }, tlast = wall_clock64();
+#endif
+  for (int r = a.r0; r < a.L; r++)
+  {
+    PKB_TICK(5);
+    // (the per-thread addresses into the vote sets would live across the whole kernel and find their home in scratch: an opaque
+    // scalar copy of the base pointer makes every column recompute them, ramx_kernels_resident.h round 3)
+    PShard *vb = a.vote;
+    asm volatile("" : "+s"(vb));
+    if (((r + 8) & 7) == 0 && r > a.r0)
+    {
+      static_for([&](auto kc) __attribute__((always_inline)) { constexpr int k = decltype(kc)::value; w[k] = w[k + 1]; }, std::make_integer_sequence<int, NW - 1>{});
+      w[NW - 1] = wnext;
+      const int kn = ((r + 8) >> 3) + NW;
+      wnext = pkb_mask_word(a.bases[(size_t)kn * a.Np + n], kn, bdy9x4);
+    }
+    // ---- vote of row r -----------------------------------------------------------------------
+    if (wave == 0)
+    {
+      long long v[4];
+      prk_wait_vote(a, vb, a.sums_in, r == a.r0, r, lane, my_shard_blocks, failed, v);
+      if (lane == 0)
+      {
+        sm.vote[r & 1][0] = v[0]; sm.vote[r & 1][1] = v[1]; sm.vote[r & 1][2] = v[2]; sm.vote[r & 1][3] = v[3];
+        sm.fail[r & 1] = failed;
+        if (failed) __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    PKB_TICK(0);                 // wave 0: vote seen (other waves: nothing)
+    __syncthreads();
+    PKB_TICK(1);                 // released by the block barrier
+    if (__builtin_amdgcn_readfirstlane(sm.fail[r & 1])) { failed = 1; break; }
+    long long curr = 0;
+    int besta = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+    {
+      // the vote is wave-uniform: the whole stop rule runs on the scalar unit (ram_extend.c:1064-1086, 1194-1223)
+      const long long vv = sm.vote[r & 1][k];
+      const long long vk = ((long long)__builtin_amdgcn_readfirstlane((int)(vv >> 32)) << 32) |
+                           (long long)(unsigned)__builtin_amdgcn_readfirstlane((int)vv);
+      if (vk > 2147483647LL || vk < -2147483648LL) ovf = 1;
+      if (vk > curr) { curr = vk; besta = k; }
+    }
+    int dist = max_row - r;
+    dist = dist < 0 ? -dist : dist;
+    const bool new_max = curr >= max_ext + (long long)dist * a.minimp;
+    if (new_max) { max_row = r; max_ext = curr; }
+    int d2 = r - max_row;
+    d2 = d2 < 0 ? -d2 : d2;
+    stopped = d2 >= a.when_to_stop;
+    rows_done = r + 1;
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.cons_out[r] = (signed char)besta;
+    // block 0 clears the vote set of row r+3 (ramx_kernels_vote.h)
+    if (blockIdx.x == 0 && threadIdx.x < NSHARD)
+    {
+      PShard *z = vb + (size_t)((r + 3) & (PRK_NSETS - 1)) * NSHARD + threadIdx.x;
+#pragma unroll
+      for (int k = 0; k < 4; k++) __hip_atomic_store(&z->word[k], 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const bool last_col = stopped || r == a.L - 1;      // the vote of row r+1 will not be consumed
+
+    // ---- a wave's four sums join the workgroup's; the last arriver sends the ticket ------------
+    auto arrive = [&](const long long t0, const long long t1, const long long t2, const long long t3) __attribute__((always_inline))
+    {
+      const int par = (r + 1) & 1;
+      const long long mine = lane == 0 ? t0 : lane == 1 ? t1 : lane == 2 ? t2 : t3;
+      int old = 0;
+      if (lane < 4) asm volatile("ds_add_u64 %0, %1" : : "v"(pkb_lds_off(&sm.tot[par][lane])), "v"(mine) : "memory");
+      if (lane == 0) asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(old) : "v"(pkb_lds_off(&sm.cnt[par])), "v"(1) : "memory");
+      old = __builtin_amdgcn_readfirstlane(old);
+      if (old == WPB - 1)
+      {
+        if (lane < 4)
+        {
+          long long t;
+          asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(t) : "v"(pkb_lds_off(&sm.tot[par][lane])) : "memory");
+          asm volatile("ds_write_b64 %0, %1" : : "v"(pkb_lds_off(&sm.tot[par][lane])), "v"(0LL) : "memory");
+          PShard *sh = vb + (size_t)((r + 1) & (PRK_NSETS - 1)) * NSHARD + shard;
+          __hip_atomic_fetch_add(&sh->word[lane], (unsigned long long)t + PRK_BIAS + PRK_TICKET, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane == 0) asm volatile("ds_write_b32 %0, %1" : : "v"(pkb_lds_off(&sm.cnt[par])), "v"(0) : "memory");
+      }
+    };
+
+    // ---- LEAN?  (ramx_kernels_resident.h: no lane can contribute more than its cap to the vote of row r+1 or set a record in
+    // row r.)  prevBest = best cell of row r-1, high = record after row r-1.  Up to leader_max lanes that fail the test
+    // (`leaders`) do not keep the wave from the LEAN row: pkb_leader_rows computes what it skipped for them.
+    const int jhi = bdy - r;
+    const int capfloor = (high + a.cap) > 0 ? (high + a.cap) : 0;
+    bool lean = false, early = false;
+    unsigned long long leaders = 0;
+    if (live && a.lean_p >= 0)
+    {
+      const unsigned long long keep = __ballot((n < a.Nx) && !((prevBest + 2 * a.lean_p <= capfloor) && (prevBest + a.lean_p <= high)));
+      if (keep == 0) { lean = true; early = true; }
+      else if (__popcll(keep) <= a.leader_max) { lean = true; leaders = keep; }
+    }
+    if (!live) early = true;
+    if (early && !last_col)
+    {
+      // this wave's contribution to row r+1 is the sum of its caps whatever the row holds (ram_extend.c:1042, 1052-1062)
+      const long long t = wave_sum_nonneg31((live && n < a.Nx) ? capfloor : 0);
+      arrive(t, t, t, t);
+    }
+    PKB_TICK(3);                 // early arrival
+
+    // ---- the band ----------------------------------------------------------------------------
+    int contrib[4] = { 0, 0, 0, 0 };       // each in [0, 2^31): clamped at 0 below, capped from below by high + cap
+    if (live)
+    {
+      const int ph4 = 4 * ((r + 8) & 7);
+      int best, kg[NG], bA[4], maxE;
+      if (lean)
+      {
+        switch (besta)
+        {
+          case 0: pkb_band<W, BLOCK, 0, false>(go2, ge2, sm.pt, ph4, w, R, E, best, kg, bA, maxE); break;
+          case 1: pkb_band<W, BLOCK, 1, false>(go2, ge2, sm.pt, ph4, w, R, E, best, kg, bA, maxE); break;
+          case 2: pkb_band<W, BLOCK, 2, false>(go2, ge2, sm.pt, ph4, w, R, E, best, kg, bA, maxE); break;
+          default: pkb_band<W, BLOCK, 3, false>(go2, ge2, sm.pt, ph4, w, R, E, best, kg, bA, maxE); break;
+        }
+        lean_rows++;
+      }
+      else
+      {
+        switch (besta)
+        {
+          case 0: pkb_band<W, BLOCK, 0, true>(go2, ge2, sm.pt, ph4, w, R, E, best, kg, bA, maxE); break;
+          case 1: pkb_band<W, BLOCK, 1, true>(go2, ge2, sm.pt, ph4, w, R, E, best, kg, bA, maxE); break;
+          case 2: pkb_band<W, BLOCK, 2, true>(go2, ge2, sm.pt, ph4, w, R, E, best, kg, bA, maxE); break;
+          default: pkb_band<W, BLOCK, 3, true>(go2, ge2, sm.pt, ph4, w, R, E, best, kg, bA, maxE); break;
+        }
+        full_rows++;
+      }
+      int rel, jbest = 0, bestA[4] = { NEG, NEG, NEG, NEG };
+      if (lean) rel = pkb_hmax(best);
+      else
+      {
+        // best cell: highest value, lowest group on ties (inside a group the key already prefers the lowest cell)
+        int bkey = kg[NG - 1], bg = NG - 1;
+        rel = kg[NG - 1] >> 16;
+#pragma unroll
+        for (int g = NG - 2; g >= 0; g--)
+        {
+          const int v = kg[g] >> 16;
+          const bool take = v >= rel;
+          rel = take ? v : rel;
+          bkey = take ? kg[g] : bkey;
+          bg = take ? g : bg;
+        }
+        jbest = 32 * bg + 31 - (bkey & 31);
+        const int mE = pkb_hmax(maxE);
+#pragma unroll
+        for (int c = 0; c < 4; c++) bestA[c] = jhi < 1 ? NEG : pbase + imax(pkb_hmax(bA[c]), mE);
+      }
+      const int bestF = jhi < 0 ? SENT : pbase + rel;      // a flank that has run out: every cell holds the sentinel (bnw_extend.c:990-1002)
+      for (unsigned long long rest = leaders; rest != 0; rest &= rest - 1)
+        pkb_leader_rows<W, BLOCK>(sm.pt, sm.lead[wave], (r + 8) & 7, __builtin_ctzll(rest), pbase, jhi, bestF, w, R, E, bestA, jbest);
+      // the base follows the row's best cell (every 16th row, when some lane's has moved far enough)
+      if ((r & 15) == 15 && __any(jhi >= 0 && (rel > a.rebase || rel < -a.rebase)))
+      {
+        const int mv = jhi >= 0 ? rel : 0;
+        const int bb = pk_two(mv);
+        static_for([&](auto kc) __attribute__((always_inline)) { constexpr int k = decltype(kc)::value; R[k] = pkb_sub_sat(R[k], bb); E[k] = pkb_sub_sat(E[k], bb); },
+                   std::make_integer_sequence<int, NP>{});
+        pbase += mv;
+      }
+      prevBest = bestF;
+      if (bestF > high) { high = bestF; pos = r + jbest - W; }   // ram_extend.c:1140-1150
+      if (new_max) { thigh = high; tpos = pos; }                  // :1203-1207
+      if (n < a.Nx)
+      {
+        const int capv = high + a.cap;
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+        {
+          const int b = bestA[c] < 0 ? 0 : bestA[c];
+          contrib[c] = (b >= capv) ? b : capv;
+        }
+      }
+    }
+    PKB_TICK(2);                 // band done
+    if (last_col) break;
+    if (!early)
+    {
+      const long long t0 = wave_sum_nonneg31(contrib[0]), t1 = wave_sum_nonneg31(contrib[1]);
+      const long long t2 = wave_sum_nonneg31(contrib[2]), t3 = wave_sum_nonneg31(contrib[3]);
+      arrive(t0, t1, t2, t3);
+    }
+    PKB_TICK(4);                 // late arrival
+  }
+#ifdef RAMX_PRK_TIMING
+  if (a.dbg != NULL && (threadIdx.x & 63) == 0)
+  {
+#pragma unroll
+    for (int k = 0; k < 6; k++) a.dbg[((size_t)blockIdx.x * WPB + wave) * 8 + k] = tsum[k];
+    a.dbg[((size_t)blockIdx.x * WPB + wave) * 8 + 6] = (unsigned long long)full_rows;
+    a.dbg[((size_t)blockIdx.x * WPB + wave) * 8 + 7] = (unsigned long long)lean_rows;
+  }
+#endif
+
+  // ---- write back: rows (so that the device state can be inspected / resumed), trim, control ----
+  if (live && rows_done > a.r0)
+  {
+    // the rows are those of row rl = rows_done - 1; cells beyond the flank's end carry the reference's fill (bnw_extend.c:990-1002)
+    const int rl = rows_done - 1, jh = bdy - rl;
+    const int edge = rl < W ? a.go + (rl + 1) * a.ge : SENT;
+    int4 *S3 = S;
+    asm volatile("" : "+v"(S3));
+    auto val = [&](int half, int j, bool is_e) __attribute__((always_inline)) -> int
+    {
+      if (j > jh) { const int f = j < W ? edge : SENT; return is_e ? f + a.ge : f; }
+      return pbase + half;
+    };
+    static_for([&](auto qc) __attribute__((always_inline))
+    {
+      constexpr int q = decltype(qc)::value;
+      const int m0 = val((int)(short)R[q], 2 * q, false), e0 = val(E[q] >> 16, 2 * q, true);
+      if constexpr (q < W)
+      {
+        const int m1 = val(R[q] >> 16, 2 * q + 1, false), e1 = val((int)(short)E[q + 1 < NP ? q + 1 : 0], 2 * q + 1, true);
+        S3[(size_t)q * 64] = make_int4(m0, e0, m1, e1);
+      }
+      else S3[(size_t)q * 64] = make_int4(m0, e0, high, pos);
+    }, std::make_integer_sequence<int, Q>{});
+    a.trim[n] = make_int2(thigh, tpos);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+  {
+    RamxCtl o;
+    o.max_ext = max_ext; o.max_row = max_row; o.stopped = stopped; o.rows_done = rows_done; o.overflow = ovf;
+    o.besta = lean_rows;           // reported as ramx_run_info.packed_rows: LEAN rows of the first wave
+    o.pad = failed;
+    *a.ctl_out = o;
+  }
+}

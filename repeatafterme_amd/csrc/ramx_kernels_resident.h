@@ -3,6 +3,7 @@
 #pragma once
 
 #include "ramx_kernels_common.h"
+#include "ramx_kernels_vote.h"
 
 // ------------------------------------------------------------------------------------------
 // persistent kernel: the whole direction in ONE launch, DP rows resident in registers
@@ -11,73 +12,10 @@
 // For W known at compile time and N <= (resident waves) x 64 the row of a flank (2 x (2W+1) int32) fits the
 // lane's registers, so the row never travels: HBM sees only the base words (~12 words per flank per column) and
 // the 32-byte vote.  All L columns run inside ONE launch; the dependent-launch boundary of the
-// streaming kernel becomes a device-wide barrier that is fused with the vote:
-//
-//   column c, every block:   4 x int64 atomicAdd into shard (blockIdx % 32) of vote set (c+1) % 4.  Each add
-//                            carries its own arrival ticket: value = partial_sum + 2^41 + 2^54, so bits 54..63 of
-//                            a shard word count the blocks that have contributed and the low 54 bits hold
-//                            sum + count * 2^41 (|partial| <= 512 lanes * 2^31 < 2^41: exact for any input).
-//   column c+1, wave 0:      lanes 0..31 poll "their" shard's four words (relaxed agent-scope loads + s_sleep,
-//                            bounded) until all four show every block of the shard, decode, shuffle-reduce and
-//                            publish the vote through LDS.  One fabric round trip after the last arrival.
-//   Four sets rotate.  Set (c+3) % 4 (last used by row c-1) is zeroed by block 0 during column c, once block 0 has seen
-//   every ticket of row c -- so everybody has finished reading row c-1.  Nobody adds to it before having seen block 0's
-//   ticket for row c+2, which wave 0 of block 0 sends at the end of column c+1, after its own poll for row c+1 -- whose
-//   s_waitcnt vmcnt(0) also drains the zeroing stores of column c (same wave).  The zeroing is complete a column before
-//   it has to be and nobody stalls for it (with three sets block 0 had to wait for its stores before every add).
-//
-// Placement independent: only agent-scope atomics / atomic loads touch shared words, no assumption on which
-// XCD a block runs.  The launch is a PLAIN one (a cooperative launch made profiled processes crash at exit, DESIGN.md
-// section 7): the host launches at most one workgroup per CU and never more workgroups than CUs, which makes the grid
-// co-resident on an idle device but is no guarantee next to a co-tenant -- correctness therefore rests on the BOUNDED
-// spins (a timeout raises `err`, every block leaves) and on the host repeating the direction with the per-column
-// launches when that happens (ramx_dev_run_direction; batch mode: ramx_dev_run_families repeats the affected
-// families).  Multi-GPU runs exchange the vote through the mailboxes below, or fall back to RCCL between per-column launches.
-
-#define PRK_NSETS 4        // rotating vote sets: row r uses set r % 4, block 0 clears the set of row r+3 in column r (protocol above)
-#ifndef PRK_SHARD_BYTES
-#define PRK_SHARD_BYTES 256   // 64 (one line per shard) measured 1.5-2 % slower: neighbouring shards share a memory channel
-#endif
-struct PShard { unsigned long long word[4]; unsigned long long pad[PRK_SHARD_BYTES / 8 - 4]; };
-
-// sum of a 64-bit value over each row of 16 lanes (every lane of the row gets it): xor-1, xor-2 butterflies inside quads,
-// then the mirrored half-row and the mirrored row (sums are uniform below each step, so a mirror reaches the other half)
-__device__ __forceinline__ unsigned long long prk_row_sum_u64(unsigned long long x)
-{
-#define PRK_SUM_STEP(ctrl) do { \
-    const unsigned lo_ = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)x, ctrl, 0xf, 0xf, false); \
-    const unsigned hi_ = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(x >> 32), ctrl, 0xf, 0xf, false); \
-    x += ((unsigned long long)hi_ << 32) | lo_; } while (0)
-  PRK_SUM_STEP(0xB1);     // quad_perm [1,0,3,2]
-  PRK_SUM_STEP(0x4E);     // quad_perm [2,3,0,1]
-  PRK_SUM_STEP(0x141);    // row_half_mirror
-  PRK_SUM_STEP(0x140);    // row_mirror
-#undef PRK_SUM_STEP
-  return x;
-}
-__device__ __forceinline__ unsigned long long prk_readlane_u64(unsigned long long x, int l)
-{
-  return ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(x >> 32), l) << 32) |
-         (unsigned)__builtin_amdgcn_readlane((int)(unsigned)x, l);
-}
-   // 64 B: one cache line per shard
-#define PRK_BIAS (1ULL << 41)
-#define PRK_TICKET (1ULL << 54)
-
-// Multi-GPU: every rank owns one PeerBox in fine-grained device memory, mapped into all other ranks through
-// hipIpc handles.  After a rank's own blocks have all contributed to a column, its block 0 stores the rank's four
-// totals into slot [set][rank] of EVERY box (its own included) over xGMI; each word carries the column number in
-// its top 16 bits, so a reader knows a word is current without any flag or fence; every block then polls the local
-// box until all ranks' words of this column are there.  3 sets rotate exactly like the vote shards.
-#define RAMX_MAX_RANKS 16
-struct PeerBox { unsigned long long slot[3][RAMX_MAX_RANKS][4]; unsigned long long token[RAMX_MAX_RANKS]; };
-// a word's tag is the low 16 bits of (row + 1): a cleared slot (tag 0) is never taken for row 0's word by a rank that
-// looks before its peer has written
-#ifndef PEER_TAG_OFFSET
-#define PEER_TAG_OFFSET 1
-#endif
-#define PEER_VBIAS (1LL << 46)
-#define PEER_VMASK ((1ULL << 48) - 1)
+// streaming kernel becomes a device-wide barrier that is fused with the vote (protocol, vote shards and the cross-device
+// mailboxes: ramx_kernels_vote.h, shared with the packed-row kernel of ramx_kernels_packed.h, which serves the flank sets
+// and scoring systems whose rows fit int16 -- this kernel keeps the others, and the first rows of flanks whose cores are
+// shorter than the band).
 
 struct PArgs
 {
@@ -100,11 +38,11 @@ struct PArgs
   int pack_ok;                  // every reachable score fits 27 bits: the fast path may pack (score, cell) keys
   int lean_p;                   // P = max(0, largest matrix entry) of the LEAN test (prk_band_fast); -1: never LEAN
   int leader_max;               // a wave with at most this many lanes that fail the LEAN test runs LEAN + prk_leader_rows (0: off)
-  int pk_ok;                    // the packed LEAN row (prk_band_pk) stays inside int16 for this scoring system and band width
+  long long *sums_next;         // != NULL: this launch runs the first L rows of a longer direction -- the sums of row L go here as
+                                // NSHARD x 4 plain int64 words (zeroed by the host) for the launch that continues
   unsigned long long *dbg;      // -DRAMX_PRK_TIMING builds only: [block][8] phase sums in 10 ns ticks
 };
 
-#define PRK_SPIN_LIMIT (1u << 21)
 #ifdef RAMX_PRK_TIMING
 #define PRK_TICK(k) do { const unsigned long long t_ = wall_clock64(); tsum[k] += t_ - tlast; tlast = t_; } while (0)
 #else
@@ -136,12 +74,6 @@ __device__ __forceinline__ int vmax3(int x, int y, int z)   // forced v_max3_i32
   int d;
   asm("v_max3_i32 %0, %1, %2, %3" : "=v"(d) : "v"(x), "v"(y), "v"(z));
   return d;
-}
-
-template <class F, int... Js>
-__device__ __forceinline__ void static_for(F &&f, std::integer_sequence<int, Js...>)
-{
-  (f(std::integral_constant<int, Js>{}), ...);
 }
 
 // Score table of the in-bounds fast path, addressed straight from the packed base stream with ONE SDWA instruction:
@@ -516,251 +448,16 @@ __device__ __forceinline__ void prk_band(const int go, const int ge, const int *
   }
 }
 
-// ------------------------------------------------------------------------------------------
-// LEAN columns with TWO CELLS of the flank's row per register (tools/microbench/pk16_band.hip)
-// ------------------------------------------------------------------------------------------
-// While a wave's columns are LEAN and all its flanks in bounds, its row is held as R[k] = (m[2k], m[2k+1]) in int16 RELATIVE to a
-// per-lane 32-bit base: every in-bounds cell of a row lies within 2W (P + |min score| + |ge|) + |go| + |ge| of the row's best
-// cell (it is reached from the best cell 2W rows back by 2W substitutions and one gap), the best cell moves by at most
-// max(P, |min score|) per row, and the base follows it every 16 rows -- the host checks that the sum stays inside int16
-// (pk_ok).  The chain-free part of the row update runs two cells per instruction, the insertion chain a cell at a time on
-// register halves (v_max3_i16 / v_add_i16 with op_sel: the other half of the destination is kept); the chain register
-// C_k = (e[2k-1], e[2k]) is the third operand of the packed m = max(sub, Pe, C_k) and, stored as dword k of the lane's LDS
-// column (the d-row's slots), the deletion pair (e[2j+1], e[2j+2]) of pair j = k-1 in the next row.  A byte of the
-// phase-aligned base word is the class pair of two cells and indexes a 256-entry table of score pairs (one table per winner,
-// built once per launch).  641 instructions per row against ~1,100 for prk_band_fast<.., LEAN>.
-// Entered (prk_pack) after PRK_PK_AFTER consecutive in-bounds LEAN columns, left (prk_unpack) before the first column that is
-// not: the other bands never see this representation.
-#ifndef PRK_PK_AFTER
-#define PRK_PK_AFTER 4
-#endif
-#define PRK_PK_REBASE 8000          // |best cell - base| that moves the base (looked at every 16th row)
-#define PRK_PK_ENTER 10000          // widest distance of a cell from the base with which a row may be packed
-
-__device__ __forceinline__ int pk_max3_lll(int a, int b, int c) { int d; asm("v_max3_i16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
-__device__ __forceinline__ int pk_max3_hhh(int a, int b, int c) { int d; asm("v_max3_i16 %0, %1, %2, %3 op_sel:[1,1,1,0]" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
-__device__ __forceinline__ void pk_add_to_hi(int &dst, int a, int b) { asm("v_add_i16 %0, %1, %2 op_sel:[0,0,1]" : "+v"(dst) : "v"(a), "v"(b)); }
-__device__ __forceinline__ int pk_add_lo(int a, int b) { int d; asm("v_add_i16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
-template <int BYTE>
-__device__ __forceinline__ unsigned pk_byte_x4(unsigned A)   // ((A >> 8*BYTE) & 0xff) << 2
-{
-  unsigned d;
-  if (BYTE == 0) asm("v_lshlrev_b32_sdwa %0, 2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(d) : "v"(A));
-  else if (BYTE == 1) asm("v_lshlrev_b32_sdwa %0, 2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(d) : "v"(A));
-  else if (BYTE == 2) asm("v_lshlrev_b32_sdwa %0, 2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(d) : "v"(A));
-  else asm("v_lshlrev_b32_sdwa %0, 2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(d) : "v"(A));
-  return d;
-}
-typedef short pk_s2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ pk_s2 pk_v(int x) { return __builtin_bit_cast(pk_s2, x); }
-__device__ __forceinline__ int pk_i(pk_s2 x) { return __builtin_bit_cast(int, x); }
-__device__ __forceinline__ int pk_two(int x) { return (x & 0xffff) | (x << 16); }
-
-// [winner][class pair]: score of the low class | score of the high class << 16.  One table per winner, entries 4 bytes apart: the
-// pair index comes from two base codes, so interleaving the winners (16-byte stride) would put a wave's 64 lookups on the
-// nine banks its low codes select -- measured: 3.2 G bank-conflict cycles per launch and no gain from the packed row
-struct PkTabs { int pair[4][256]; };
-
-__device__ __forceinline__ void pk_tabs_init(PkTabs &pt, const int (&tab)[RAMX_NCLASS][4])
-{
-  if (threadIdx.x < 256)
-  {
-    const int lo = threadIdx.x & 15, hi = threadIdx.x >> 4;
-#pragma unroll
-    for (int c = 0; c < 4; c++)
-      pt.pair[c][threadIdx.x] = ((lo < RAMX_NCLASS ? tab[lo][c] : 0) & 0xffff) | ((hi < RAMX_NCLASS ? tab[hi][c] : 0) << 16);
-  }
-}
-
-// one LEAN row; returns the row's best cell relative to the base.  CSEL: the winner (compile-time: its dword of a table row
-// is part of the LDS instruction's offset)
-template <int W, int BLOCK, int CSEL>
-__device__ __forceinline__ int prk_band_pk(const int go, const int ge, const PkTabs &pt, int *sE, const int r,
-                                           const unsigned (&w)[(2 * W + 1 + 8) / 8 + 2], int (&R)[W + 1])
-{
-  constexpr int B = 2 * W + 1, NP = W + 1, PT = 2;
-  const int go2 = pk_two(go), ge2 = pk_two(ge), neg2 = (int)0x80008000u;
-  const int ph4 = 4 * ((r + 8) & 7);
-  int *myE = sE + threadIdx.x;
-  const char *tb = reinterpret_cast<const char *>(&pt.pair[CSEL][0]);
-  int C = neg2, best = neg2;            // C.lo = e of the cell before the pair
-  unsigned A = 0;
-  int tQ[PT], eQ[PT];
-#pragma unroll
-  for (int k = 0; k < PT; k++) eQ[k] = k + 1 < NP ? myE[(k + 1) * BLOCK] : neg2;
-  auto lookup = [&](auto kc) __attribute__((always_inline))
-  {
-    constexpr int k = decltype(kc)::value;
-    if constexpr ((k & 3) == 0) A = __builtin_amdgcn_alignbit(w[(k >> 2) + 1], w[k >> 2], ph4);
-    return *reinterpret_cast<const int *>(tb + pk_byte_x4<(k & 3)>(A));
-  };
-  static_for([&](auto kc) __attribute__((always_inline)) { tQ[decltype(kc)::value] = lookup(kc); }, std::make_integer_sequence<int, PT>{});
-  static_for([&](auto kc) __attribute__((always_inline))
-  {
-    constexpr int k = decltype(kc)::value;
-    if constexpr ((k & 1) == 0)
-    {
-      asm volatile("" ::"v"(best), "v"(C));
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    const int S = tQ[0], PeP = eQ[0];
-#pragma unroll
-    for (int q = 0; q + 1 < PT; q++) { tQ[q] = tQ[q + 1]; eQ[q] = eQ[q + 1]; }
-    if constexpr (k + PT < NP) tQ[PT - 1] = lookup(std::integral_constant<int, (k + PT < NP ? k + PT : 0)>{});
-    if constexpr (k + 1 + PT < NP) eQ[PT - 1] = myE[(k + 1 + PT) * BLOCK];
-    else eQ[PT - 1] = neg2;
-    const int sub = pk_i(pk_v(R[k]) + pk_v(S));                 // bnw_extend.c:950-956, two cells
-    const int sg = pk_i(pk_v(sub) + pk_v(go2));
-    const int t = pk_max3_lll(sg, PeP, C);                      // cell 2k: max(sub + go, del, ins), :1007-1018
-    pk_add_to_hi(C, t, ge2);                                    // C = (e[2k-1], e[2k])
-    int m = pk_i(__builtin_elementwise_max(__builtin_elementwise_max(pk_v(sub), pk_v(PeP)), pk_v(C)));
-    myE[k * BLOCK] = C;
-    if constexpr (2 * k + 1 < B)
-    {
-      const int t2 = pk_max3_hhh(sg, PeP, C);                   // cell 2k+1
-      C = pk_add_lo(t2, ge2);                                   // the next pair's chain register: lo = e[2k+1]
-    }
-    else m = (m & 0xffff) | (int)0x80000000u;                   // there is no cell 2W+1
-    R[k] = m;
-    best = pk_i(__builtin_elementwise_max(pk_v(best), pk_v(m)));
-  }, std::make_integer_sequence<int, NP>{});
-  const pk_s2 bp = pk_v(best);
-  return bp.x > bp.y ? (int)bp.x : (int)bp.y;
-}
-
-// int32 row + d-row  ->  packed row + chain-register row, base = `base`.  False (nothing changed) unless every lane's cells
-// lie within PRK_PK_ENTER of its base.
-template <int W, int BLOCK>
-__device__ __forceinline__ bool prk_pack(const int (&M)[2 * W + 1], short *sD, const int base, int (&R)[W + 1])
-{
-  constexpr int B = 2 * W + 1, NP = W + 1;
-  int lo = M[0], hi = M[0];
-#pragma unroll
-  for (int j = 1; j < B; j++) { lo = M[j] < lo ? M[j] : lo; hi = M[j] > hi ? M[j] : hi; }
-  if (!__all((hi - base <= PRK_PK_ENTER) && (base - lo <= PRK_PK_ENTER))) return false;
-  int *myW = reinterpret_cast<int *>(sD) + threadIdx.x;
-  int prevD = 0;
-#pragma unroll
-  for (int k = 0; k < NP; k++)
-  {
-    const int cur = myW[k * BLOCK];                             // d[2k] | d[2k+1] << 16
-    const int elo = k > 0 ? M[2 * k - 1] + (prevD >> 16) - base : -32768;
-    const int ehi = M[2 * k] + (int)(short)cur - base;
-    myW[k * BLOCK] = (elo & 0xffff) | (ehi << 16);
-    const int mhi = 2 * k + 1 < B ? M[2 * k + 1 < B ? 2 * k + 1 : 0] - base : -32768;
-    R[k] = ((M[2 * k] - base) & 0xffff) | (mhi << 16);
-    prevD = cur;
-  }
-  return true;
-}
-
-template <int W, int BLOCK>
-__device__ __forceinline__ void prk_unpack(const int (&R)[W + 1], short *sD, const int base, int (&M)[2 * W + 1])
-{
-  constexpr int B = 2 * W + 1, NP = W + 1;
-  int *myW = reinterpret_cast<int *>(sD) + threadIdx.x;
-  int Cc = myW[0];
-#pragma unroll
-  for (int p = 0; p < NP; p++)
-  {
-    const int Cn = p + 1 < NP ? myW[(p + 1 < NP ? p + 1 : 0) * BLOCK] : 0;
-    const int mlo = (int)(short)R[p], mhi = R[p] >> 16;
-    const int d0 = (Cc >> 16) - mlo;
-    const int d1 = 2 * p + 1 < B ? (int)(short)Cn - mhi : 0;
-    myW[p * BLOCK] = (d0 & 0xffff) | (d1 << 16);
-    M[2 * p] = base + mlo;
-    if constexpr (true) { if (2 * p + 1 < B) M[2 * p + 1 < B ? 2 * p + 1 : 0] = base + mhi; }
-    Cc = Cn;
-  }
-}
-
-// the base follows the row's best cell (bestRel, relative): rows and chain registers move by -bestRel
-template <int W, int BLOCK>
-__device__ __forceinline__ void prk_pk_rebase(int (&R)[W + 1], int *sE, const int bestRel)
-{
-  constexpr int NP = W + 1;
-  const pk_s2 bb = { (short)bestRel, (short)bestRel };
-  int *myE = sE + threadIdx.x;
-#pragma unroll
-  for (int k = 0; k < NP; k++) R[k] = pk_i(pk_v(R[k]) - bb);
-#pragma unroll
-  for (int k = 0; k < NP; k++) myE[k * BLOCK] = pk_i(pk_v(myE[k * BLOCK]) - bb);
-}
-
-// prk_leader_rows on the packed row: the leader's lane publishes its row in true values; e_k comes from the chain registers
-template <int W, int BLOCK>
-__device__ __forceinline__ void prk_leader_rows_pk(const FastTabs &ft, const int *sE, int *scr, const int r, const int leader, const int base,
-                                                   const unsigned (&w)[(2 * W + 1 + 8) / 8 + 2], const int (&R)[W + 1], LaneDP &D)
-{
-  constexpr int B = 2 * W + 1, NW = (B + 8) / 8 + 2, NP = W + 1;
-  constexpr int NH = (B + 63) / 64;
-  const int lane = threadIdx.x & 63;
-  if (lane == leader)
-  {
-    // the packed registers as they are (W + 1 stores, no arithmetic on the wave that every workgroup waits for)
-#pragma unroll
-    for (int k = 0; k < NP; k++) scr[k] = R[k];
-#pragma unroll
-    for (int k = 0; k < NW; k++) scr[NP + k] = (int)w[k];
-  }
-  __builtin_amdgcn_wave_barrier();
-  const int ph = (r + 8) & 7;
-  const int thr = (threadIdx.x & ~63) + leader;
-  const int bf = __builtin_amdgcn_readlane(D.bestF, leader);
-  const int lbase = __builtin_amdgcn_readlane(base, leader);
-  int ta[4] = { NEG, NEG, NEG, NEG }, me = NEG;
-  unsigned long long hit[NH];
-#pragma unroll
-  for (int h = 0; h < NH; h++)
-  {
-    const int k = lane + 64 * h;
-    const bool ok = k < B;
-    const int kk = ok ? k : 0;
-    const int mw = scr[kk >> 1];
-    const int m = lbase + ((kk & 1) ? (mw >> 16) : (int)(short)mw);
-    const int g = kk + 1 + ph;
-    const unsigned cls = ((unsigned)scr[NP + (g >> 3)] >> (4 * (g & 7))) & 15u;
-    const int sv = ft.row[cls][0];
-    if (ok)
-    {
-      ta[0] = imax(ta[0], add_sext_byte<0>(m, sv)); ta[1] = imax(ta[1], add_sext_byte<1>(m, sv));
-      ta[2] = imax(ta[2], add_sext_byte<2>(m, sv)); ta[3] = imax(ta[3], add_sext_byte<3>(m, sv));
-      if (k >= 1)
-      {
-        const int cw = sE[((kk + 1) >> 1) * BLOCK + thr];        // C_{(k+1)/2} = (e[k] | .) for odd k, (. | e[k]) for even k
-        me = imax(me, lbase + ((kk & 1) ? (int)(short)cw : (cw >> 16)));
-      }
-    }
-    hit[h] = __ballot(ok && m == bf);
-  }
-  const int mx = wave_max_i32_dpp(me);
-  int best[4];
-#pragma unroll
-  for (int c = 0; c < 4; c++) best[c] = imax(wave_max_i32_dpp(ta[c]), mx);
-  int jb = 0;
-#pragma unroll
-  for (int h = NH - 1; h >= 0; h--)
-    if (hit[h]) jb = 64 * h + __builtin_ctzll(hit[h]);
-  if (lane == leader)
-  {
-#pragma unroll
-    for (int c = 0; c < 4; c++) D.bestA[c] = best[c];
-    D.jbest = jb;
-  }
-}
-
 // W = 80 (161 cells per lane): one wave per SIMD only, so that the row has the whole register file of the lane (the
 // accumulation registers take what the 256 architectural ones cannot hold)
 template <int W, int BLOCK>
 __global__ __launch_bounds__(BLOCK, (W > 40 ? 1 : 2)) void ramx_persistent_kernel(const PArgs a)
 {
   constexpr int B = 2 * W + 1, Q = W + 1, NW = (B + 8) / 8 + 2, WPB = BLOCK / 64, RS = 2 * BLOCK;   // RS: shorts per cell-pair row of sD
-  constexpr bool PKC = W <= 40;          // the packed LEAN rows exist for the two-waves-per-SIMD widths
   // one object, tables first: their LDS addresses must fit the 16-bit offset field of the ds_read that uses them
   struct Smem
   {
     FastTabs ft;
-    PkTabs pk;                                         // score pairs of two cells, per winner (packed LEAN rows)
     int tab4[4][TAB_ROWS * TAB_STRIDE];                // one score table per winner base (masked path)
     long long red[WPB][4];
     long long vote[4];
@@ -786,8 +483,6 @@ __global__ __launch_bounds__(BLOCK, (W > 40 ? 1 : 2)) void ramx_persistent_kerne
   int M[B];
   int high, pos, thigh = 0, tpos = 0;
   int prevBest = 0x3fffffff;             // best cell of the previous row (LEAN test): unknown before the first band of this launch
-  int leanrun = 0;                       // consecutive in-bounds LEAN columns of this wave (scalar)
-  int pk_cols = 0;                       // columns this wave ran on the packed row (reported for wave 0 of workgroup 0)
   {
 #pragma unroll
     for (int q = 0; q < W; q++)
@@ -815,7 +510,6 @@ __global__ __launch_bounds__(BLOCK, (W > 40 ? 1 : 2)) void ramx_persistent_kerne
     s_tab4[bt][e] = v;
   }
   fast_tabs_init<BLOCK>(s_ft, a.tab);
-  if constexpr (PKC) pk_tabs_init(sm.pk, a.tab);
   __syncthreads();
 
 #ifdef RAMX_PRK_TIMING
@@ -837,108 +531,8 @@ __global__ __launch_bounds__(BLOCK, (W > 40 ? 1 : 2)) void ramx_persistent_kerne
     // ---- vote of row r -----------------------------------------------------------------------
     if (wave == 0)
     {
-      long long v[4] = { 0, 0, 0, 0 };
-      if (r == 0)
-      {
-        if (lane < NSHARD) { const long long *p = a.sums0 + lane * 4; v[0] = p[0]; v[1] = p[1]; v[2] = p[2]; v[3] = p[3]; }
-      }
-      else
-      {
-        // lane = shard + 32 * half polls words 2*half, 2*half+1 of "its" shard: one 16-byte load per lane and round
-        // (a quarter of the requests of four 8-byte loads on 32 lanes; the poll competes with the adds it waits for)
-        const int sidx = lane & (NSHARD - 1), half = lane >> 5;
-        const unsigned long long *src = &a.vote[(size_t)(r & (PRK_NSETS - 1)) * NSHARD + sidx].word[2 * half];
-        unsigned spins = 0;
-        bool done = my_shard_blocks <= 0 || (a.nranks > 1 && blockIdx.x != 0);   // multi-rank: only the exchanger needs the local total
-#ifdef PRK_PROBE_NO_WAIT
-        done = true;         // timing probe (wrong results by construction): nobody waits for the vote, the winner rotates
-#endif
-        unsigned long long x0 = 0, x1 = 0;
-        for (;;)
-        {
-          if (!done)
-          {
-            typedef unsigned v4u __attribute__((ext_vector_type(4)));
-            v4u q;
-            asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(q) : "v"(src) : "memory");
-            x0 = ((unsigned long long)q.y << 32) | q.x;
-            x1 = ((unsigned long long)q.w << 32) | q.z;
-            done = (x0 >> 54) >= (unsigned long long)my_shard_blocks && (x1 >> 54) >= (unsigned long long)my_shard_blocks;
-          }
-          if (__all(done)) break;
-          if (++spins > PRK_SPIN_LIMIT || ((spins & 1023u) == 0 && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0))
-          {
-            failed = 1;
-            break;
-          }
-          __builtin_amdgcn_s_sleep(1);
-        }
-        // fold the 32 shards: the raw words first (sum + bias and ticket fields are both additive: at most 256 tickets,
-        // ten bits), rows of 16 lanes with DPP butterflies, the four rows on the scalar unit; one decode per word
-        if (my_shard_blocks <= 0 || failed || (a.nranks > 1 && blockIdx.x != 0)) { x0 = 0; x1 = 0; }
-        x0 = prk_row_sum_u64(x0); x1 = prk_row_sum_u64(x1);
-        const unsigned long long t0 = prk_readlane_u64(x0, 0) + prk_readlane_u64(x0, 16), t1 = prk_readlane_u64(x1, 0) + prk_readlane_u64(x1, 16);
-        const unsigned long long t2 = prk_readlane_u64(x0, 32) + prk_readlane_u64(x0, 48), t3 = prk_readlane_u64(x1, 32) + prk_readlane_u64(x1, 48);
-        v[0] = (long long)(t0 & (PRK_TICKET - 1)) - (long long)(t0 >> 54) * (long long)PRK_BIAS;
-        v[1] = (long long)(t1 & (PRK_TICKET - 1)) - (long long)(t1 >> 54) * (long long)PRK_BIAS;
-        v[2] = (long long)(t2 & (PRK_TICKET - 1)) - (long long)(t2 >> 54) * (long long)PRK_BIAS;
-        v[3] = (long long)(t3 & (PRK_TICKET - 1)) - (long long)(t3 >> 54) * (long long)PRK_BIAS;
-#ifdef PRK_PROBE_NO_WAIT
-        v[0] = (r & 3) == 0; v[1] = (r & 3) == 1; v[2] = (r & 3) == 2; v[3] = (r & 3) == 3;
-#endif
-      }
-      if (r == 0)
-      {
-#pragma unroll
-        for (int k = 0; k < 4; k++) v[k] = wave_sum_ll(v[k]);
-      }
-      if (a.nranks > 1 && r > 0 && !failed)
-      {
-        // ---- cross-device step: v[] is this rank's total (identical in all lanes) -----------
-        const unsigned long long tag = (unsigned long long)((r + PEER_TAG_OFFSET) & 0xffff) << 48;
-        if (blockIdx.x == 0 && lane < a.nranks)
-        {
-          PeerBox *pb = a.peers[lane];
-#pragma unroll
-          for (int k = 0; k < 4; k++)
-          {
-            if (v[k] >= PEER_VBIAS || v[k] <= -PEER_VBIAS) failed = 1;     // cannot be encoded: fail loudly
-            __hip_atomic_store(&pb->slot[r % 3][a.rank][k], tag | ((unsigned long long)(v[k] + PEER_VBIAS) & PEER_VMASK),
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-          }
-        }
-        unsigned long long y[4] = { 0, 0, 0, 0 };
-        bool got = lane >= a.nranks;
-        unsigned spins = 0;
-        const PeerBox *pollbox = (a.mirror != NULL && blockIdx.x != 0) ? a.mirror : a.box;
-        for (;;)
-        {
-          if (!got)
-          {
-#pragma unroll
-            for (int k = 0; k < 4; k++) y[k] = __hip_atomic_load(&pollbox->slot[r % 3][lane][k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            got = (y[0] >> 48) == (tag >> 48) && (y[1] >> 48) == (tag >> 48) && (y[2] >> 48) == (tag >> 48) && (y[3] >> 48) == (tag >> 48);
-            if (got && a.mirror != NULL && blockIdx.x == 0)
-            {
-              // this rank's word of this column has arrived: pass it on to the local pollers
-#pragma unroll
-              for (int k = 0; k < 4; k++)
-                __hip_atomic_store(&a.mirror->slot[r % 3][lane][k], y[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-          }
-          if (__all(got)) break;
-          if (++spins > PRK_SPIN_LIMIT || ((spins & 1023u) == 0 && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0))
-          {
-            failed = 1;
-            break;
-          }
-          __builtin_amdgcn_s_sleep(1);
-        }
-        failed = __any(failed) ? 1 : 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-          v[k] = wave_sum_ll((lane < a.nranks && !failed) ? (long long)(y[k] & PEER_VMASK) - PEER_VBIAS : 0LL);
-      }
+      long long v[4];
+      prk_wait_vote(a, a.vote, a.sums0, r == 0, r, lane, my_shard_blocks, failed, v);
       {
         // the winner's substitution column of the fast-path tables (same argmax rule as below, ram_extend.c:1064-1086)
         long long cw = 0;
@@ -1040,7 +634,6 @@ __global__ __launch_bounds__(BLOCK, (W > 40 ? 1 : 2)) void ramx_persistent_kerne
       }
       else prk_band<W, true, BLOCK>(a.go, a.ge, s_tab, s_ft, sD, r, w, jlo, jhi, M, D);
       prevBest = D.bestF;
-      if constexpr (PKC) leanrun = __builtin_amdgcn_readfirstlane((a.pk_ok && all_in && lean) ? leanrun + 1 : 0);
       if (D.bestF > high) { high = D.bestF; pos = r + D.jbest - W; }   // ram_extend.c:1140-1150
       if (new_max) { thigh = high; tpos = pos; }                        // :1203-1207
       if (n < a.Nx)
@@ -1055,7 +648,8 @@ __global__ __launch_bounds__(BLOCK, (W > 40 ? 1 : 2)) void ramx_persistent_kerne
       }
     }
     PRK_TICK(2);                 // band done
-    if (stopped || r == a.L - 1) break;     // the vote of row r+1 will not be consumed
+    const bool hand_over = a.sums_next != NULL && !stopped && r == a.L - 1;     // another launch continues with row L
+    if (!hand_over && (stopped || r == a.L - 1)) break;     // the vote of row r+1 will not be consumed
     {
       long long tot[4];
       // (one reduction instead of four when a plain LEAN column makes the four sums equal was measured: 7.46 against 7.21 us
@@ -1075,293 +669,17 @@ __global__ __launch_bounds__(BLOCK, (W > 40 ? 1 : 2)) void ramx_persistent_kerne
       long long t = 0;
 #pragma unroll
       for (int wv = 0; wv < WPB; wv++) t += s_red[wv][threadIdx.x];
-      PShard *sh = a.vote + (size_t)((r + 1) & (PRK_NSETS - 1)) * NSHARD + shard;
-      __hip_atomic_fetch_add(&sh->word[threadIdx.x], (unsigned long long)t + PRK_BIAS + PRK_TICKET, __ATOMIC_RELAXED,
-                             __HIP_MEMORY_SCOPE_AGENT);
-    }
-    PRK_TICK(4);                 // contribution issued
-    // ---- packed LEAN columns (prk_band_pk): after PRK_PK_AFTER in-bounds LEAN columns the wave packs its row and runs the
-    // following columns in a loop of its own -- the same vote, stop rule, sums and ticket (every wave of the workgroup meets the
-    // same two barriers per column in either loop), the band on the packed row -- until a column is not an in-bounds LEAN
-    // one (known BEFORE the column starts: the test needs the previous row's best cell and the bounds only); then it unpacks and
-    // this loop goes on.  R is defined by prk_pack and M by prk_unpack on the only way out: neither row is live in the other's loop.
-    if constexpr (PKC)
-    {
-      if (leanrun >= PRK_PK_AFTER)
+      if (hand_over)
+        __hip_atomic_fetch_add(&a.sums_next[shard * 4 + threadIdx.x], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else
       {
-        leanrun = 0;
-        int R[W + 1];
-        if (prk_pack<W, BLOCK>(M, sD, prevBest, R))
-        {
-          int pbase = prevBest;
-          bool fin = false;
-          int rr = r + 1;
-          int *sE = reinterpret_cast<int *>(sD);
-          for (; rr < a.L; rr++)
-          {
-            const int r = rr;                 // the copied column code below calls its column r
-            const int jlo = bd.x - r, jhi = bd.y - r;
-            unsigned long long leaders = 0;
-            {
-              const bool all_in = __all((n >= a.Nx) || ((jlo <= 0) && (jhi >= B)));
-              const int capfloor = (high + a.cap) > 0 ? (high + a.cap) : 0;
-              const unsigned long long keep = __ballot((n < a.Nx) && !((prevBest + 2 * a.lean_p <= capfloor) && (prevBest + a.lean_p <= high)));
-              if (!all_in || (keep != 0 && __popcll(keep) > a.leader_max)) break;
-              leaders = keep;
-            }
-            unsigned w[NW];
-            int besta = 0;
-            bool new_max = false;
-            // The per-thread addresses into the vote sets are live across the whole kernel and have their home in scratch (the
-            // outer loop runs at the register limit); reloading them here put two scratch round trips in front of the ticket and
-            // one at the loop top (-DRAMX_PRK_TIMING: "issue atomics" 0.28 -> 0.82 us, "loop top" 0.1 -> 0.7-1.0 us).  An opaque
-            // copy of the base pointer in scalar registers makes this loop recompute them instead.
-            PShard *vb = a.vote;
-            asm volatile("" : "+s"(vb));
-            auto pre = [&]() __attribute__((always_inline)) -> bool
-            {
-            PRK_TICK(5);
-            // ---- base words of this column (independent of the vote: issued before the wait) -------
-            // (Keeping the NW words across columns and loading one new word every eighth column was tried: they are live across the
-            // whole loop then, the allocator spills them, and scratch reloads replace the L2 loads one for one.)
-            {
-              const unsigned *bp = a.bases + (size_t)((r + 8) >> 3) * a.Np + n;
-        #pragma unroll
-              for (int k = 0; k < NW; k++) w[k] = bp[(size_t)k * a.Np];
-            }
-            // ---- vote of row r -----------------------------------------------------------------------
-            if (wave == 0)
-            {
-              long long v[4] = { 0, 0, 0, 0 };
-              if (r == 0)
-              {
-                if (lane < NSHARD) { const long long *p = a.sums0 + lane * 4; v[0] = p[0]; v[1] = p[1]; v[2] = p[2]; v[3] = p[3]; }
-              }
-              else
-              {
-                // lane = shard + 32 * half polls words 2*half, 2*half+1 of "its" shard: one 16-byte load per lane and round
-                // (a quarter of the requests of four 8-byte loads on 32 lanes; the poll competes with the adds it waits for)
-                const int sidx = lane & (NSHARD - 1), half = lane >> 5;
-                const unsigned long long *src = &vb[(size_t)(r & (PRK_NSETS - 1)) * NSHARD + sidx].word[2 * half];
-                unsigned spins = 0;
-                bool done = my_shard_blocks <= 0 || (a.nranks > 1 && blockIdx.x != 0);   // multi-rank: only the exchanger needs the local total
-        #ifdef PRK_PROBE_NO_WAIT
-                done = true;         // timing probe (wrong results by construction): nobody waits for the vote, the winner rotates
-        #endif
-                unsigned long long x0 = 0, x1 = 0;
-                for (;;)
-                {
-                  if (!done)
-                  {
-                    typedef unsigned v4u __attribute__((ext_vector_type(4)));
-                    v4u q;
-                    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(q) : "v"(src) : "memory");
-                    x0 = ((unsigned long long)q.y << 32) | q.x;
-                    x1 = ((unsigned long long)q.w << 32) | q.z;
-                    done = (x0 >> 54) >= (unsigned long long)my_shard_blocks && (x1 >> 54) >= (unsigned long long)my_shard_blocks;
-                  }
-                  if (__all(done)) break;
-                  if (++spins > PRK_SPIN_LIMIT || ((spins & 1023u) == 0 && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0))
-                  {
-                    failed = 1;
-                    break;
-                  }
-                  __builtin_amdgcn_s_sleep(1);
-                }
-                // fold the 32 shards: the raw words first (sum + bias and ticket fields are both additive: at most 256 tickets,
-                // ten bits), rows of 16 lanes with DPP butterflies, the four rows on the scalar unit; one decode per word
-                if (my_shard_blocks <= 0 || failed || (a.nranks > 1 && blockIdx.x != 0)) { x0 = 0; x1 = 0; }
-                x0 = prk_row_sum_u64(x0); x1 = prk_row_sum_u64(x1);
-                const unsigned long long t0 = prk_readlane_u64(x0, 0) + prk_readlane_u64(x0, 16), t1 = prk_readlane_u64(x1, 0) + prk_readlane_u64(x1, 16);
-                const unsigned long long t2 = prk_readlane_u64(x0, 32) + prk_readlane_u64(x0, 48), t3 = prk_readlane_u64(x1, 32) + prk_readlane_u64(x1, 48);
-                v[0] = (long long)(t0 & (PRK_TICKET - 1)) - (long long)(t0 >> 54) * (long long)PRK_BIAS;
-                v[1] = (long long)(t1 & (PRK_TICKET - 1)) - (long long)(t1 >> 54) * (long long)PRK_BIAS;
-                v[2] = (long long)(t2 & (PRK_TICKET - 1)) - (long long)(t2 >> 54) * (long long)PRK_BIAS;
-                v[3] = (long long)(t3 & (PRK_TICKET - 1)) - (long long)(t3 >> 54) * (long long)PRK_BIAS;
-        #ifdef PRK_PROBE_NO_WAIT
-                v[0] = (r & 3) == 0; v[1] = (r & 3) == 1; v[2] = (r & 3) == 2; v[3] = (r & 3) == 3;
-        #endif
-              }
-              if (r == 0)
-              {
-        #pragma unroll
-                for (int k = 0; k < 4; k++) v[k] = wave_sum_ll(v[k]);
-              }
-              if (a.nranks > 1 && r > 0 && !failed)
-              {
-                // ---- cross-device step: v[] is this rank's total (identical in all lanes) -----------
-                const unsigned long long tag = (unsigned long long)((r + PEER_TAG_OFFSET) & 0xffff) << 48;
-                if (blockIdx.x == 0 && lane < a.nranks)
-                {
-                  PeerBox *pb = a.peers[lane];
-        #pragma unroll
-                  for (int k = 0; k < 4; k++)
-                  {
-                    if (v[k] >= PEER_VBIAS || v[k] <= -PEER_VBIAS) failed = 1;     // cannot be encoded: fail loudly
-                    __hip_atomic_store(&pb->slot[r % 3][a.rank][k], tag | ((unsigned long long)(v[k] + PEER_VBIAS) & PEER_VMASK),
-                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                  }
-                }
-                unsigned long long y[4] = { 0, 0, 0, 0 };
-                bool got = lane >= a.nranks;
-                unsigned spins = 0;
-                const PeerBox *pollbox = (a.mirror != NULL && blockIdx.x != 0) ? a.mirror : a.box;
-                for (;;)
-                {
-                  if (!got)
-                  {
-        #pragma unroll
-                    for (int k = 0; k < 4; k++) y[k] = __hip_atomic_load(&pollbox->slot[r % 3][lane][k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    got = (y[0] >> 48) == (tag >> 48) && (y[1] >> 48) == (tag >> 48) && (y[2] >> 48) == (tag >> 48) && (y[3] >> 48) == (tag >> 48);
-                    if (got && a.mirror != NULL && blockIdx.x == 0)
-                    {
-                      // this rank's word of this column has arrived: pass it on to the local pollers
-        #pragma unroll
-                      for (int k = 0; k < 4; k++)
-                        __hip_atomic_store(&a.mirror->slot[r % 3][lane][k], y[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                  }
-                  if (__all(got)) break;
-                  if (++spins > PRK_SPIN_LIMIT || ((spins & 1023u) == 0 && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0))
-                  {
-                    failed = 1;
-                    break;
-                  }
-                  __builtin_amdgcn_s_sleep(1);
-                }
-                failed = __any(failed) ? 1 : 0;
-        #pragma unroll
-                for (int k = 0; k < 4; k++)
-                  v[k] = wave_sum_ll((lane < a.nranks && !failed) ? (long long)(y[k] & PEER_VMASK) - PEER_VBIAS : 0LL);
-              }
-              {
-                // the winner's substitution column of the fast-path tables (same argmax rule as below, ram_extend.c:1064-1086)
-                long long cw = 0;
-                int bw = 0;
-        #pragma unroll
-                for (int k = 0; k < 4; k++)
-                  if (v[k] > cw) { cw = v[k]; bw = k; }
-                fast_tabs_winner(s_ft, s_tab4[bw], lane);
-              }
-              if (lane == 0)
-              {
-                s_vote[0] = v[0]; s_vote[1] = v[1]; s_vote[2] = v[2]; s_vote[3] = v[3];
-                s_fail = failed;
-                if (failed) __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              }
-            }
-            PRK_TICK(0);                 // wave 0: vote seen (other waves: nothing)
-            __syncthreads();
-            PRK_TICK(1);                 // released by the block barrier
-            if (__builtin_amdgcn_readfirstlane(s_fail)) { failed = 1; return false; }
-            long long curr = 0;
-            besta = 0;
-        #pragma unroll
-            for (int k = 0; k < 4; k++)
-            {
-              // the vote is wave-uniform: move it to scalar registers so that the whole stop rule runs on the SALU and
-              // none of its state (max_ext, max_row, ...) occupies vector registers next to the row
-              const long long vv = s_vote[k];
-              const long long vk = ((long long)__builtin_amdgcn_readfirstlane((int)(vv >> 32)) << 32) |
-                                   (long long)(unsigned)__builtin_amdgcn_readfirstlane((int)vv);
-              if (vk > 2147483647LL || vk < -2147483648LL) ovf = 1;
-              if (vk > curr) { curr = vk; besta = k; }
-            }
-            int dist = max_row - r;
-            dist = dist < 0 ? -dist : dist;
-            new_max = curr >= max_ext + (long long)dist * a.minimp;
-            if (new_max) { max_row = r; max_ext = curr; }
-            int d2 = r - max_row;
-            d2 = d2 < 0 ? -d2 : d2;
-            stopped = d2 >= a.when_to_stop;
-            rows_done = r + 1;
-            if (blockIdx.x == 0 && threadIdx.x == 0) a.cons_out[r] = (signed char)besta;
-            // block 0 clears the vote set of row r+3 (see the protocol above)
-            if (blockIdx.x == 0 && threadIdx.x < NSHARD)
-            {
-              PShard *z = vb + (size_t)((r + 3) & (PRK_NSETS - 1)) * NSHARD + threadIdx.x;
-        #pragma unroll
-              for (int k = 0; k < 4; k++) __hip_atomic_store(&z->word[k], 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-
-              return true;
-            };
-            if (!pre()) { fin = true; break; }
-            int contrib[4] = { 0, 0, 0, 0 };
-            {
-              LaneDP D;
-              D.eC = NEG; D.mPrev = NEG - 1000000; D.jbest = 0;
-#pragma unroll
-              for (int c = 0; c < 4; c++) { D.eA[c] = NEG; D.bestA[c] = NEG; }
-              int rel;
-              switch (besta)
-              {
-                case 0: rel = prk_band_pk<W, BLOCK, 0>(a.go, a.ge, sm.pk, sE, r, w, R); break;
-                case 1: rel = prk_band_pk<W, BLOCK, 1>(a.go, a.ge, sm.pk, sE, r, w, R); break;
-                case 2: rel = prk_band_pk<W, BLOCK, 2>(a.go, a.ge, sm.pk, sE, r, w, R); break;
-                default: rel = prk_band_pk<W, BLOCK, 3>(a.go, a.ge, sm.pk, sE, r, w, R); break;
-              }
-              D.bestF = pbase + rel;
-              pk_cols++;
-              for (unsigned long long rest = leaders; rest != 0; rest &= rest - 1)
-                prk_leader_rows_pk<W, BLOCK>(s_ft, sE, sm.lead[wave], r, __builtin_ctzll(rest), pbase, w, R, D);
-              if ((r & 15) == 15 && __any(rel > PRK_PK_REBASE || rel < -PRK_PK_REBASE))
-              {
-                prk_pk_rebase<W, BLOCK>(R, sE, rel);
-                pbase += rel;
-              }
-              prevBest = D.bestF;
-              if (D.bestF > high) { high = D.bestF; pos = r + D.jbest - W; }   // ram_extend.c:1140-1150 (leaders only)
-              if (new_max) { thigh = high; tpos = pos; }                        // :1203-1207
-              if (n < a.Nx)
-              {
-                const int capv = high + a.cap;
-#pragma unroll
-                for (int c = 0; c < 4; c++)
-                {
-                  const int b = D.bestA[c] < 0 ? 0 : D.bestA[c];
-                  contrib[c] = (b >= capv) ? b : capv;
-                }
-              }
-            }
-            auto post = [&]() __attribute__((always_inline)) -> bool
-            {
-            PRK_TICK(2);                 // band done
-            if (stopped || r == a.L - 1) return false;     // the vote of row r+1 will not be consumed
-            {
-              long long tot[4];
-              // (one reduction instead of four when a plain LEAN column makes the four sums equal was measured: 7.46 against 7.21 us
-              // per column -- the allocator's answer to the extra branch costs more than the 45 instructions)
-        #pragma unroll
-              for (int c = 0; c < 4; c++) tot[c] = wave_sum_nonneg31(contrib[c]);
-              if (lane == 0)
-              {
-        #pragma unroll
-                for (int c = 0; c < 4; c++) s_red[wave][c] = tot[c];
-              }
-            }
-            __syncthreads();
-            PRK_TICK(3);                 // wave reduction + block barrier
-            if (threadIdx.x < 4)
-            {
-              long long t = 0;
-        #pragma unroll
-              for (int wv = 0; wv < WPB; wv++) t += s_red[wv][threadIdx.x];
-              PShard *sh = vb + (size_t)((r + 1) & (PRK_NSETS - 1)) * NSHARD + shard;
-              __hip_atomic_fetch_add(&sh->word[threadIdx.x], (unsigned long long)t + PRK_BIAS + PRK_TICKET, __ATOMIC_RELAXED,
-                                     __HIP_MEMORY_SCOPE_AGENT);
-            }
-            PRK_TICK(4);                 // contribution issued
-              return true;
-            };
-            if (!post()) { fin = true; break; }
-          }
-          prk_unpack<W, BLOCK>(R, sD, pbase, M);
-          if (fin || rr >= a.L) break;
-          r = rr - 1;                          // the column that broke the run is this loop's next one
-        }
+        PShard *sh = a.vote + (size_t)((r + 1) & (PRK_NSETS - 1)) * NSHARD + shard;
+        __hip_atomic_fetch_add(&sh->word[threadIdx.x], (unsigned long long)t + PRK_BIAS + PRK_TICKET, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
       }
     }
+    PRK_TICK(4);                 // contribution issued
+    if (hand_over) break;
   }
 #ifdef RAMX_PRK_TIMING
   if (a.dbg != NULL && (threadIdx.x & 63) == 0)
@@ -1388,7 +706,7 @@ __global__ __launch_bounds__(BLOCK, (W > 40 ? 1 : 2)) void ramx_persistent_kerne
   if (blockIdx.x == 0 && threadIdx.x == 0)
   {
     RamxCtl o;
-    o.max_ext = max_ext; o.max_row = max_row; o.stopped = stopped; o.rows_done = rows_done; o.overflow = ovf; o.besta = pk_cols;
+    o.max_ext = max_ext; o.max_row = max_row; o.stopped = stopped; o.rows_done = rows_done; o.overflow = ovf; o.besta = 0;
     o.pad = failed;
     *a.ctl_out = o;
   }

@@ -1,0 +1,89 @@
+// ramx_packed.hip -- third translation unit of libramx's device code: the packed-row persistent kernel (ramx_kernels_packed.h)
+// and its launcher.  Kept apart from ramx_device.hip so that the translation units compile side by side.
+#define RAMX_SECONDARY_TU 1
+#include "ramx_kernels_packed.h"
+
+#include <stdlib.h>
+
+#define PK_REBASE 6000
+
+int ramx_pk_plan(int W, int go, int ge, const int (&tab)[RAMX_NCLASS][4], int *spread, int *rebase)
+{
+  *spread = 0; *rebase = 0;
+  if (!(W == 14 || W == 20 || W == 40 || W == 80) || go > 0 || ge > 0 || getenv("RAMX_NO_PK") != NULL) return 0;
+  long long P = 0, mn = 0;
+  for (int c = 0; c < RAMX_NCLASS; c++)
+    for (int k = 0; k < 4; k++)
+    {
+      if (tab[c][k] > P) P = tab[c][k];
+      if (-(long long)tab[c][k] > mn) mn = -(long long)tab[c][k];
+    }
+  const long long GO = -(long long)go, GE = -(long long)ge;
+  // an in-bounds cell lies at most `sp` below its row's best cell (ramx_kernels_packed.h); the base lags the best cell by at most
+  // PK_REBASE + 16 max(P, mn); sub + go of the lowest cell needs mn + GO more, e of it GO + GE
+  const long long sp = 3LL * W * (P + mn + GE) + GO + (long long)W * GE;
+  const long long lag = PK_REBASE + 16 * (P > mn ? P : mn);
+  if (sp + lag + mn + GO + GE + 64 > 32000) return 0;
+  if (lag + P + 64 > 32000) return 0;
+  *spread = (int)sp; *rebase = PK_REBASE;
+  return 1;
+}
+
+template <int W, int BLOCK>
+static int pk_capacity(int *out)
+{
+  int per_cu = 0, dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return RAMX_ERR_HIP;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return RAMX_ERR_HIP;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ramx_packed_kernel<W, BLOCK>, BLOCK, 0) != hipSuccess) return RAMX_ERR_HIP;
+  if (per_cu > 1) per_cu = 1;          // one workgroup per CU by design (one barrier participant per CU)
+  *out = per_cu * cus;
+  return RAMX_OK;
+}
+
+template <int W>
+static int pk_shape(int tiles, int *block, int *blocks)
+{
+  int cap = 0, rc;
+  *block = 0; *blocks = 0;
+  // one wave per SIMD while the flank set allows it, two above
+  if ((rc = pk_capacity<W, 256>(&cap)) != RAMX_OK) return rc;
+  if ((tiles + 3) / 4 <= cap) { *block = 256; *blocks = (tiles + 3) / 4; return RAMX_OK; }
+  if ((rc = pk_capacity<W, 512>(&cap)) != RAMX_OK) return rc;
+  if ((tiles + 7) / 8 <= cap) { *block = 512; *blocks = (tiles + 7) / 8; }
+  return RAMX_OK;
+}
+
+int ramx_pk_shape(int W, int tiles, int *block, int *blocks)
+{
+  switch (W)
+  {
+    case 14: return pk_shape<14>(tiles, block, blocks);
+    case 20: return pk_shape<20>(tiles, block, blocks);
+    case 40: return pk_shape<40>(tiles, block, blocks);
+    case 80: return pk_shape<80>(tiles, block, blocks);
+  }
+  *block = 0; *blocks = 0;
+  return RAMX_OK;
+}
+
+template <int W>
+static int pk_launch(hipStream_t st, int block, int blocks, const PKArgs &a)
+{
+  if (block == 256) hipLaunchKernelGGL((ramx_packed_kernel<W, 256>), dim3(blocks), dim3(256), 0, st, a);
+  else if (block == 512) hipLaunchKernelGGL((ramx_packed_kernel<W, 512>), dim3(blocks), dim3(512), 0, st, a);
+  else return RAMX_ERR_ARG;
+  return hipGetLastError() == hipSuccess ? RAMX_OK : RAMX_ERR_HIP;
+}
+
+int ramx_pk_launch(hipStream_t st, int W, int block, int blocks, const PKArgs &a)
+{
+  switch (W)
+  {
+    case 14: return pk_launch<14>(st, block, blocks, a);
+    case 20: return pk_launch<20>(st, block, blocks, a);
+    case 40: return pk_launch<40>(st, block, blocks, a);
+    case 80: return pk_launch<80>(st, block, blocks, a);
+  }
+  return RAMX_ERR_UNSUPPORTED;
+}

@@ -32,6 +32,7 @@ class RunInfo:
     lanes_per_flank: int = 1
     respeculated_rows: int = 0
     packed_rows: int = 0
+    lean_rows: int = 0
 
 
 def _params(p: ExtendParams):

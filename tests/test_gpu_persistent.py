@@ -201,16 +201,21 @@ def test_lean_band_switches_on_and_off_exactly(W, matrix, gap, short_frac, monke
         monkeypatch.delenv("RAMX_NO_LEAN")
         assert lean[0].persistent == 1 and lean[0].lanes_per_flank == 1
         runs = [lean]
-        # the packed row (prk_band_pk: two cells per register in relative int16, entered after a few in-bounds LEAN columns,
-        # left before the first column that is not one): really taken at the two-waves-per-SIMD widths, never with RAMX_NO_PK,
-        # and the rows it hands back (prk_unpack) are compared cell by cell below like every other run's
-        # (packed_rows counts the first wave's columns: with flanks that end early in it that wave may never qualify)
-        if short_frac == 0.0:
-            assert (lean[0].packed_rows > 100) == (W <= 40), (W, lean[0].packed_rows)
+        # the packed-row kernel (csrc/ramx_kernels_packed.h: two cells per register in relative int16) takes every column from
+        # the first one in which no flank has a low out-of-bounds cell (the 12-base cores here: row W - 12), LEAN rows included;
+        # RAMX_NO_PK=1 keeps the whole direction on the int32 rows.  The rows it writes back are compared cell by cell below
+        # like every other run's
+        assert lean[0].packed_rows >= L - W and lean[0].lean_rows > 100, (W, lean[0].packed_rows, lean[0].lean_rows)
+        assert full[0].packed_rows >= L - W and full[0].lean_rows == 0
         monkeypatch.setenv("RAMX_NO_PK", "1")
         runs.append(_run_device(fs, p, 1, monkeypatch, True))
         monkeypatch.delenv("RAMX_NO_PK")
-        assert runs[-1][0].packed_rows == 0 and full[0].packed_rows == 0
+        assert runs[-1][0].packed_rows == 0
+        monkeypatch.setenv("RAMX_NO_PK", "1")
+        monkeypatch.setenv("RAMX_NO_LEAN", "1")
+        runs.append(_run_device(fs, p, 1, monkeypatch, True))         # the int32 rows without the LEAN band: the plainest reference
+        monkeypatch.delenv("RAMX_NO_PK")
+        monkeypatch.delenv("RAMX_NO_LEAN")
         # the leader path (prk_leader_rows: a wave with a few lanes that fail the LEAN test runs LEAN and computes those
         # lanes' candidate rows and best cell with all its lanes): off, and for any number of such lanes per wave
         for lm in ("0", "64"):
