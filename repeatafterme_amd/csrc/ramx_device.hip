@@ -798,6 +798,8 @@ static int prk_run(ramx_dev *d, const KArgs &a, int L, bool *used)
     ka.when_to_stop = a.when_to_stop; ka.nblocks = pk_blocks;
     memcpy(ka.tab, a.tab, sizeof(ka.tab));
     ka.lean_p = pa.lean_p; ka.leader_max = pa.leader_max;
+    ka.spec_on = getenv("RAMX_NO_PK_SPEC") == NULL ? 1 : 0;
+    { const char *we = getenv("RAMX_TEST_PK_WRONG_EVERY"); ka.test_wrong_every = we ? atoi(we) : 0; }
     rc = ramx_pk_launch(d->stream, W, pk_block, pk_blocks, ka);
     if (rc != RAMX_OK) ramx_set_error("packed-row kernel: launch failed (W %d, %d workgroups of %d threads)", W, pk_blocks, pk_block);
     d->last_packed_r0 = pk_r0;
@@ -1699,7 +1701,8 @@ extern "C" int ramx_dev_run_direction(ramx_dev *d, ramx_run_info *info)
     info->lanes_per_flank = lanes;
     info->respeculated_rows = cp_done ? f.besta : 0;
     info->packed_rows = (persistent && !cp_done && d->last_packed_r0 >= 0 && f.rows_done > d->last_packed_r0) ? f.rows_done - d->last_packed_r0 : 0;
-    info->lean_rows = (persistent && !cp_done && d->last_packed_r0 >= 0) ? f.besta : 0;
+    info->lean_rows = (persistent && !cp_done && d->last_packed_r0 >= 0) ? (f.besta & 0xffff) : 0;
+    if (persistent && !cp_done && d->last_packed_r0 >= 0) info->respeculated_rows = (f.besta >> 16) & 0xffff;
   }
   return RAMX_OK;
 }

@@ -65,9 +65,15 @@ struct PkCfg
 };
 
 #define PKB_NEG2 ((int)0x80008000u)
+#ifndef PKB_GROUP
+#define PKB_GROUP 2          // pairs of cells between scheduling barriers
+#endif
+#ifndef PKB_PT
+#define PKB_PT 2             // table rows are looked up this many pairs ahead of their use
+#endif
 
-__device__ __forceinline__ int pkb_add_sat(int a, int b) { int d; asm("v_pk_add_i16 %0, %1, %2 clamp" : "=v"(d) : "v"(a), "v"(b)); return d; }
-__device__ __forceinline__ int pkb_sub_sat(int a, int b) { int d; asm("v_pk_sub_i16 %0, %1, %2 clamp" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ int pkb_add_sat(int a, int b) { return pk_i(__builtin_elementwise_add_sat(pk_v(a), pk_v(b))); }      // v_pk_add_i16 .. clamp
+__device__ __forceinline__ int pkb_sub_sat(int a, int b) { return pk_i(__builtin_elementwise_sub_sat(pk_v(a), pk_v(b))); }      // v_pk_sub_i16 .. clamp
 __device__ __forceinline__ int pkb_max(int a, int b) { return pk_i(__builtin_elementwise_max(pk_v(a), pk_v(b))); }
 // dst.hi = sat(a.lo + b.lo), dst.lo kept
 __device__ __forceinline__ void pkb_add_to_hi(int &dst, int a, int b) { asm("v_add_i16 %0, %1, %2 op_sel:[0,0,1] clamp" : "+v"(dst) : "v"(a), "v"(b)); }
@@ -86,10 +92,15 @@ __device__ __forceinline__ unsigned pkb_mask_word(unsigned wv, int kb, int bdy9x
   return wv | m;
 }
 
+// Score tables, indexed by (winner << 8 | class pair byte): the band forms that index in the 16-bit halves of two registers per
+// four cell pairs (v_perm_b32 of the phase-aligned base word with the winner), so ONE pair of band instantiations serves the four
+// winners -- four instantiations under a switch meet in a block whose every row register is a PHI, and the allocator then keeps
+// two rows in flight.
 struct PkTabs
 {
-  int4 t4[256];           // [class pair byte]: the four candidates' score pairs (low class | high class << 16): FULL rows
-  int tp[4][256];         // [winner][class pair byte]: LEAN rows (entries 4 bytes apart: see ramx_kernels_resident.h)
+  int4 t4[4][256];        // FULL rows: the four candidates' score pairs (low class | high class << 16), ROTATED so that .x is the
+                          // winner's: (w, w+1, w+2, w+3 mod 4)
+  int tp[4][256];         // LEAN rows: the winner's score pair (entries 4 bytes apart: see ramx_kernels_resident.h)
 };
 
 template <int BLOCK>
@@ -107,20 +118,21 @@ __device__ __forceinline__ void pkb_tabs_init(PkTabs &pt, const int (&tab)[RAMX_
       q[c] = (sl & 0xffff) | (sh << 16);
       pt.tp[c][i] = q[c];
     }
-    pt.t4[i] = make_int4(q[0], q[1], q[2], q[3]);
+#pragma unroll
+    for (int wv = 0; wv < 4; wv++) pt.t4[wv][i] = make_int4(q[wv], q[(wv + 1) & 3], q[(wv + 2) & 3], q[(wv + 3) & 3]);
   }
 }
 
-// One row on the packed representation.  CSEL: the winner (compile time: its dword of a table row is a register of the loaded
-// quad / its table's address is part of the instruction's offset).  ph4: 4 x the nibble phase of step 0 in w[0].
-// FULL: kg[] = best cell keys per group of 32 cells, bA[] = the candidates' running maxima (packed), maxE = max e (packed);
-// LEAN: best = the row's best value (packed halves).
-template <int W, int BLOCK, int CSEL, bool FULL>
-__device__ __forceinline__ void pkb_band(const int go2, const int ge2, const PkTabs &pt, const int ph4, const unsigned (&w)[PkCfg<W>::NW],
+// One row on the packed representation.  wsel: the winner (wave-uniform; part of the table index).  ph4: 4 x the nibble phase of
+// step 0 in w[0].  FULL: kg[] = best cell keys per group of 32 cells, bA[i] = running maximum (packed) of candidate
+// (wsel + i) mod 4, maxE = max e (packed); LEAN: best = the row's best value (packed halves).
+template <int W, int BLOCK, bool FULL>
+__device__ __forceinline__ void pkb_band(const int go2, const int ge2, const PkTabs &pt, const int wsel, const int ph4, const unsigned (&w)[PkCfg<W>::NW],
                                          int (&R)[PkCfg<W>::NP], int (&E)[PkCfg<W>::NP], int &best, int (&kg)[PkCfg<W>::NG], int (&bA)[4], int &maxE)
 {
-  constexpr int B = PkCfg<W>::B, NP = PkCfg<W>::NP, NG = PkCfg<W>::NG, PT = 2;
-  const char *tb = FULL ? reinterpret_cast<const char *>(&pt.t4[0]) : reinterpret_cast<const char *>(&pt.tp[CSEL][0]);
+  constexpr int B = PkCfg<W>::B, NP = PkCfg<W>::NP, NG = PkCfg<W>::NG, PT = PKB_PT;
+  const char *tb = FULL ? reinterpret_cast<const char *>(&pt.t4[0][0]) : reinterpret_cast<const char *>(&pt.tp[0][0]);
+  const unsigned wrep = (unsigned)wsel * 0x01010101u;
   const int hmask = (int)0xffff0000u;
   int C = PKB_NEG2, Rprev = PKB_NEG2;
   best = PKB_NEG2; maxE = PKB_NEG2;
@@ -128,26 +140,32 @@ __device__ __forceinline__ void pkb_band(const int go2, const int ge2, const PkT
   for (int c = 0; c < 4; c++) bA[c] = PKB_NEG2;
 #pragma unroll
   for (int g = 0; g < NG; g++) kg[g] = -2147483647 - 1;
-  unsigned A = 0;
+  unsigned Alo = 0, Ahi = 0;          // (winner << 8 | class pair byte) of four cell pairs, one per 16-bit half
   int tQ[PT];
   int cQ[FULL ? PT : 1][4];
   auto lookup = [&](auto kc, auto qc) __attribute__((always_inline))
   {
     constexpr int k = decltype(kc)::value, qi = decltype(qc)::value;
-    if constexpr ((k & 3) == 0) A = __builtin_amdgcn_alignbit(w[(k >> 2) + 1], w[k >> 2], ph4);
+    if constexpr ((k & 3) == 0)
+    {
+      const unsigned A = __builtin_amdgcn_alignbit(w[(k >> 2) + 1], w[k >> 2], ph4);
+      Alo = __builtin_amdgcn_perm(wrep, A, 0x04010400u);
+      Ahi = __builtin_amdgcn_perm(wrep, A, 0x04030402u);
+    }
+    const unsigned Aw = (k & 2) ? Ahi : Alo;
     if constexpr (FULL)
     {
-      const int4 v4 = *reinterpret_cast<const int4 *>(tb + pk_byte_shl<(k & 3), 4>(A));
+      const int4 v4 = *reinterpret_cast<const int4 *>(tb + pk_word_shl<(k & 1), 4>(Aw));
       cQ[qi][0] = v4.x; cQ[qi][1] = v4.y; cQ[qi][2] = v4.z; cQ[qi][3] = v4.w;
-      tQ[qi] = CSEL == 0 ? v4.x : CSEL == 1 ? v4.y : CSEL == 2 ? v4.z : v4.w;
+      tQ[qi] = v4.x;
     }
-    else tQ[qi] = *reinterpret_cast<const int *>(tb + pk_byte_shl<(k & 3), 2>(A));
+    else tQ[qi] = *reinterpret_cast<const int *>(tb + pk_word_shl<(k & 1), 2>(Aw));
   };
   static_for([&](auto kc) __attribute__((always_inline)) { lookup(kc, kc); }, std::make_integer_sequence<int, PT>{});
   static_for([&](auto kc) __attribute__((always_inline))
   {
     constexpr int k = decltype(kc)::value;
-    if constexpr ((k & 1) == 0)
+    if constexpr ((k % PKB_GROUP) == 0)
     {
       // pin the accumulators to their group (a sunk accumulation keeps every table row alive, as in prk_band_fast)
       if constexpr (FULL) asm volatile("" ::"v"(C), "v"(bA[0]), "v"(bA[1]), "v"(bA[2]), "v"(bA[3]), "v"(maxE), "v"(kg[(k > 0 ? 2 * k - 1 : 0) >> 5]));
@@ -272,15 +290,20 @@ __device__ __forceinline__ void pkb_leader_rows(const PkTabs &pt, int *scr /* [2
 template <int W, int BLOCK>
 __global__ __launch_bounds__(BLOCK, BLOCK / 256) void ramx_packed_kernel(const PKArgs a)
 {
-  constexpr int B = PkCfg<W>::B, NP = PkCfg<W>::NP, NW = PkCfg<W>::NW, NG = PkCfg<W>::NG, Q = PkCfg<W>::Q, WPB = BLOCK / 64;
+  constexpr int NP = PkCfg<W>::NP, NW = PkCfg<W>::NW, NG = PkCfg<W>::NG, Q = PkCfg<W>::Q, WPB = BLOCK / 64;
+  // rows may run one unconfirmed step ahead of the vote where a second copy of the row fits the registers
+  constexpr bool SPEC = W <= 40;
   struct Smem      // tables first: their LDS addresses must fit the 16-bit offset field of the ds_read that uses them
   {
     PkTabs pt;
-    long long tot[2][4];                               // the workgroup's four sums of the next row, by column parity
-    long long vote[2][4];                              // by column parity: a straggler may still read row r's while the vote wave writes row r+1's
-    int cnt[2];                                        // waves that have added theirs
-    int fail[2];
+    long long tot[2][2][4];                            // the workgroup's four sums of the next row: [on the guess | confirmed][column parity]
+    int word[2][2];                                    // by column parity: { decision(r): winner | new maximum << 2 | stop << 3 | failure << 4,
+                                                       //   guess(r+1): informative << 8 | argmax of the workgroup's totals }
+    int cnt[2][2];                                     // waves that have added theirs
+    int st[4];                                         // the stop rule's state, kept by the vote wave: max_ext (2 words), max_row, overflow
     int lead[WPB][2 * NP + NW + 1];                    // pkb_leader_rows: a leader's row, chain registers and base words, per wave
+    int eb[SPEC ? BLOCK * NP : 1];                     // the chain registers of row r-1 while row r stands on a guess: [thread][pair]
+                                                       // (NP is odd: a wave's 64 columns start in different banks)
   };
   __shared__ __attribute__((aligned(16))) Smem sm;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -292,30 +315,36 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 256) void ramx_packed_kernel(const P
   // last in-bounds band cell of row r: jhi = bdy - r.  Padding lanes (no flank: an all-N base stream, their vote is masked) are
   // never clipped; an empty flank has no in-bounds cell in any row
   const int bdy = (n >= a.Nx) ? 0x3fffffff : (bd.x > bd.y ? -0x40000000 : bd.y);
-  const int bdy9x4 = bdy > 0x07ffffff ? 0x3fffffff : (bdy < -0x08000000 ? -0x40000000 : 4 * (bdy + 9));
+#define PKB_BDY9X4(b) ((b) > 0x07ffffff ? 0x3fffffff : ((b) < -0x08000000 ? -0x40000000 : 4 * ((b) + 9)))
   const int shard = blockIdx.x % NSHARD;
-  const int my_shard_blocks = (a.nblocks - (lane & (NSHARD - 1)) + NSHARD - 1) / NSHARD;   // wave 0: blocks arriving on shard `lane & 31`
   const int go2 = pk_two(a.go), ge2 = pk_two(a.ge);
 
   pkb_tabs_init<BLOCK>(sm.pt, a.tab);
-  if (threadIdx.x < 8) (&sm.tot[0][0])[threadIdx.x] = 0;
-  if (threadIdx.x < 2) sm.cnt[threadIdx.x] = 0;
-  if (threadIdx.x < 2) sm.fail[threadIdx.x] = 0;
+  if (threadIdx.x < 16) (&sm.tot[0][0][0])[threadIdx.x] = 0;
+  if (threadIdx.x < 4) (&sm.cnt[0][0])[threadIdx.x] = 0;
+  if (threadIdx.x < 4) (&sm.word[0][0])[threadIdx.x] = 0;
 
   // ---- stop-rule state and records so far -------------------------------------------------------
   long long max_ext = 0;
   int max_row = -1, rows_done = a.r0, ovf = 0, stopped = 0, failed = 0;
-  int thigh = 0, tpos = 0;
+  // the snapshot of the records (ram_extend.c:1203-1207) goes straight to a.trim on every new-maximum column (8 bytes per flank,
+  // coalesced): two registers less to carry through the loop
   if (a.r0 > 0)
   {
-    const RamxCtl ci = *a.ctl_in;
-    max_ext = ci.max_ext; max_row = ci.max_row; rows_done = ci.rows_done; ovf = ci.overflow;
-    stopped = ci.stopped || ci.rows_done < a.r0;       // the launch before this one stopped (or gave up) early
-    failed = ci.pad;
-    const int2 t = a.trim[n];
-    thigh = t.x; tpos = t.y;
+    // (wave-uniform: through the scalar unit, so that the stop rule's state lives in scalar registers from the start)
+    const RamxCtl *cp = a.ctl_in;
+    const long long me = cp->max_ext;
+    max_ext = ((long long)__builtin_amdgcn_readfirstlane((int)(me >> 32)) << 32) | (long long)(unsigned)__builtin_amdgcn_readfirstlane((int)me);
+    max_row = __builtin_amdgcn_readfirstlane(cp->max_row);
+    rows_done = __builtin_amdgcn_readfirstlane(cp->rows_done);
+    ovf = __builtin_amdgcn_readfirstlane(cp->overflow);
+    stopped = (__builtin_amdgcn_readfirstlane(cp->stopped) || rows_done < a.r0) ? 1 : 0;       // the launch before this one stopped (or gave up) early
+    const int cpad = __builtin_amdgcn_readfirstlane(cp->pad);
+    failed = cpad;
   }
+  else if (live) a.trim[n] = make_int2(0, 0);
   const bool skip = stopped || failed || a.r0 >= a.L;
+  if (threadIdx.x == 0) { sm.st[0] = (int)max_ext; sm.st[1] = (int)(max_ext >> 32); sm.st[2] = max_row; sm.st[3] = ovf; }
 
   // ---- row state -> packed registers -----------------------------------------------------------
   int R[NP], E[NP];
@@ -392,17 +421,28 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 256) void ramx_packed_kernel(const P
   {
     const int k0 = (a.r0 + 8) >> 3;
     const unsigned *bp = a.bases + (size_t)k0 * a.Np + n;
-    static_for([&](auto kc) __attribute__((always_inline)) { constexpr int k = decltype(kc)::value; w[k] = pkb_mask_word(bp[(size_t)k * a.Np], k0 + k, bdy9x4); },
+    static_for([&](auto kc) __attribute__((always_inline)) { constexpr int k = decltype(kc)::value; w[k] = pkb_mask_word(bp[(size_t)k * a.Np], k0 + k, PKB_BDY9X4(bdy)); },
                std::make_integer_sequence<int, NW>{});
-    wnext = pkb_mask_word(bp[(size_t)NW * a.Np], k0 + NW, bdy9x4);
+    wnext = bp[(size_t)NW * a.Np];
   }
   __syncthreads();
 
   int prevBest = 0x3fffffff;             // best cell of the previous row (LEAN test): unknown before the first band of this launch
-  int full_rows = 0, lean_rows = 0;      // wave 0 of workgroup 0: rows by variant (reported)
+  int full_rows = 0, lean_rows = 0, wrong_rows = 0;      // wave 0 of workgroup 0: rows by variant, rows computed twice (reported)
 #ifdef RAMX_PRK_TIMING
   unsigned long long tsum[6] = { 0, 0, 0, 0, 0, 0 }, tlast = wall_clock64();
 #endif
+  // A column's vote needs two trips through the memory fabric (~2.5 us between the last ticket and the moment every workgroup
+  // has seen the sums).  A workgroup therefore does not wait for it when its OWN sums of row r say something about the winner
+  // (they differ): every wave computes row r against the argmax of the workgroup's sums (`guess`), derives records and
+  // contributions, and only then does the vote wave look at the device's vote -- which has been travelling meanwhile.  Guess
+  // right (nearly always while the flanks align, and always in a workgroup that holds the leader flank behind the end of the
+  // alignment): the workgroup's ticket for row r+1 leaves at once.  Guess wrong: the saved row r-1 and records come back, row r is
+  // computed again with the winner, and the sums are sent then.  Nothing computed from an unconfirmed guess leaves the
+  // workgroup, and a row is only ever one unconfirmed step ahead, so results cannot differ from the lock-step order.  A
+  // workgroup whose sums are all equal (all its flanks at their caps) knows nothing about the winner: it waits for the vote
+  // as before, but its LEAN waves have sent their sums before the band, so the exchange runs beside its band as well.
+  int spec = 0, guess = 0;               // this column: compute on the workgroup's own argmax before the vote is known
   for (int r = a.r0; r < a.L; r++)
   {
     PKB_TICK(5);
@@ -413,185 +453,313 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 256) void ramx_packed_kernel(const P
     if (((r + 8) & 7) == 0 && r > a.r0)
     {
       static_for([&](auto kc) __attribute__((always_inline)) { constexpr int k = decltype(kc)::value; w[k] = w[k + 1]; }, std::make_integer_sequence<int, NW - 1>{});
-      w[NW - 1] = wnext;
       const int kn = ((r + 8) >> 3) + NW;
-      wnext = pkb_mask_word(a.bases[(size_t)kn * a.Np + n], kn, bdy9x4);
+      int nn = n, bb = bdy;
+      asm volatile("" : "+v"(nn), "+v"(bb));           // (address and mask are formed here, not carried through the loop)
+      w[NW - 1] = pkb_mask_word(wnext, kn - 1, PKB_BDY9X4(bb));      // the word loaded eight columns ago (unmasked until now: nobody waited for it)
+      wnext = a.bases[(size_t)kn * a.Np + nn];
     }
-    // ---- vote of row r -----------------------------------------------------------------------
-    if (wave == 0)
-    {
-      long long v[4];
-      prk_wait_vote(a, vb, a.sums_in, r == a.r0, r, lane, my_shard_blocks, failed, v);
-      if (lane == 0)
-      {
-        sm.vote[r & 1][0] = v[0]; sm.vote[r & 1][1] = v[1]; sm.vote[r & 1][2] = v[2]; sm.vote[r & 1][3] = v[3];
-        sm.fail[r & 1] = failed;
-        if (failed) __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
-    PKB_TICK(0);                 // wave 0: vote seen (other waves: nothing)
-    __syncthreads();
-    PKB_TICK(1);                 // released by the block barrier
-    if (__builtin_amdgcn_readfirstlane(sm.fail[r & 1])) { failed = 1; break; }
-    long long curr = 0;
-    int besta = 0;
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-    {
-      // the vote is wave-uniform: the whole stop rule runs on the scalar unit (ram_extend.c:1064-1086, 1194-1223)
-      const long long vv = sm.vote[r & 1][k];
-      const long long vk = ((long long)__builtin_amdgcn_readfirstlane((int)(vv >> 32)) << 32) |
-                           (long long)(unsigned)__builtin_amdgcn_readfirstlane((int)vv);
-      if (vk > 2147483647LL || vk < -2147483648LL) ovf = 1;
-      if (vk > curr) { curr = vk; besta = k; }
-    }
-    int dist = max_row - r;
-    dist = dist < 0 ? -dist : dist;
-    const bool new_max = curr >= max_ext + (long long)dist * a.minimp;
-    if (new_max) { max_row = r; max_ext = curr; }
-    int d2 = r - max_row;
-    d2 = d2 < 0 ? -d2 : d2;
-    stopped = d2 >= a.when_to_stop;
-    rows_done = r + 1;
-    if (blockIdx.x == 0 && threadIdx.x == 0) a.cons_out[r] = (signed char)besta;
-    // block 0 clears the vote set of row r+3 (ramx_kernels_vote.h)
-    if (blockIdx.x == 0 && threadIdx.x < NSHARD)
-    {
-      PShard *z = vb + (size_t)((r + 3) & (PRK_NSETS - 1)) * NSHARD + threadIdx.x;
-#pragma unroll
-      for (int k = 0; k < 4; k++) __hip_atomic_store(&z->word[k], 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    const bool last_col = stopped || r == a.L - 1;      // the vote of row r+1 will not be consumed
+    const int par = r & 1, npar = (r + 1) & 1;
+    int besta = 0, next_guess = 0;
+    long long dgw = 0;
+    bool new_max = false, last_col = false;
 
-    // ---- a wave's four sums join the workgroup's; the last arriver sends the ticket ------------
-    auto arrive = [&](const long long t0, const long long t1, const long long t2, const long long t3) __attribute__((always_inline))
+    // ---- the vote of row r: the vote wave waits for it and publishes; everybody applies winner and stop rule ------------------
+    // The vote wave alone folds the vote and runs the stop rule (every workgroup's comes to the same result: block 0's goes to
+    // ctl_out); what the other waves need of it is ONE word: winner, new maximum, stop, failure.  It sits next to the guess the
+    // last arriver of this column leaves for the next one (sm.word[par] = { decision(r), guess(r+1) }: one LDS read per column).
+    auto decide = [&]() __attribute__((always_inline)) -> bool
     {
-      const int par = (r + 1) & 1;
+      if (wave == 0)
+      {
+        long long v[4];
+        int lv = lane;
+        asm volatile("" : "+v"(lv));                   // (per-lane addresses of the poll are formed here, not carried through the loop)
+        prk_wait_vote(a, vb, a.sums_in, r == a.r0, r, lv, (a.nblocks - (lv & (NSHARD - 1)) + NSHARD - 1) / NSHARD, failed, v);
+        const int fl = __any(failed) ? 1 : 0;
+        // the stop rule's state lives in LDS between columns (only this wave touches it): in registers it would be carried by
+        // every wave of the workgroup
+        long long mx = ((long long)__builtin_amdgcn_readfirstlane(sm.st[1]) << 32) | (long long)(unsigned)__builtin_amdgcn_readfirstlane(sm.st[0]);
+        int mr = __builtin_amdgcn_readfirstlane(sm.st[2]), ov = __builtin_amdgcn_readfirstlane(sm.st[3]);
+        long long cw = 0;
+        int bw = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+        {
+          // the vote is wave-uniform: the whole stop rule runs on the scalar unit (ram_extend.c:1064-1086, 1194-1223)
+          const long long vk = ((long long)__builtin_amdgcn_readfirstlane((int)(v[k] >> 32)) << 32) |
+                               (long long)(unsigned)__builtin_amdgcn_readfirstlane((int)v[k]);
+          if (vk > 2147483647LL || vk < -2147483648LL) ov = 1;
+          if (vk > cw) { cw = vk; bw = k; }
+        }
+        int dist = mr - r;
+        dist = dist < 0 ? -dist : dist;
+        const int nm = cw >= mx + (long long)dist * a.minimp ? 1 : 0;
+        if (nm && !fl) { mr = r; mx = cw; }
+        int d2 = r - mr;
+        d2 = d2 < 0 ? -d2 : d2;
+        const int st = d2 >= a.when_to_stop ? 1 : 0;
+        if (lane == 0)
+        {
+          sm.st[0] = (int)mx; sm.st[1] = (int)(mx >> 32); sm.st[2] = mr; sm.st[3] = ov;
+          sm.word[par][0] = bw | (nm << 2) | (st << 3) | (fl << 4);
+          if (fl) __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (blockIdx.x == 0 && !fl)
+        {
+          if (lane == 0) a.cons_out[r] = (signed char)bw;
+          // block 0 clears the vote set of row r+3 (ramx_kernels_vote.h)
+          if (lane < NSHARD)
+          {
+            PShard *z = vb + (size_t)((r + 3) & (PRK_NSETS - 1)) * NSHARD + lane;
+#pragma unroll
+            for (int k = 0; k < 4; k++) __hip_atomic_store(&z->word[k], 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+      }
+      PKB_TICK(0);                 // wave 0: vote seen, decision made (other waves: nothing)
+      // (s_waitcnt lgkmcnt(0) + s_barrier, not __syncthreads(): that would also wait for the base word and the snapshot in flight)
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      PKB_TICK(1);                 // released by the block barrier
+      int dw, gw;
+      asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(dgw) : "v"(pkb_lds_off(&sm.word[par][0])) : "memory");
+      dw = __builtin_amdgcn_readfirstlane((int)dgw); gw = __builtin_amdgcn_readfirstlane((int)(dgw >> 32));
+      next_guess = gw;
+      if (dw & 16) { failed = 1; return false; }
+      besta = dw & 3;
+      new_max = (dw & 4) != 0;
+      stopped = (dw >> 3) & 1;
+      rows_done = r + 1;
+      last_col = stopped || r == a.L - 1;      // the vote of row r+1 will not be consumed
+      return true;
+    };
+
+    // ---- a wave's four sums of row r+1 join the workgroup's.  Two sets of totals: set 1 takes sums computed from the
+    // CONFIRMED row r (its last arriver sends the ticket), set 0 those computed on the guess (sent by the vote wave once the
+    // vote has confirmed it).  The last arriver also leaves the next column's guess: the argmax of the totals (same rule as the
+    // vote, ram_extend.c:1081-1085), and whether they say anything at all.
+    auto arrive = [&](const int set, const long long t0, const long long t1, const long long t2, const long long t3) __attribute__((always_inline))
+    {
       const long long mine = lane == 0 ? t0 : lane == 1 ? t1 : lane == 2 ? t2 : t3;
       int old = 0;
-      if (lane < 4) asm volatile("ds_add_u64 %0, %1" : : "v"(pkb_lds_off(&sm.tot[par][lane])), "v"(mine) : "memory");
-      if (lane == 0) asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(old) : "v"(pkb_lds_off(&sm.cnt[par])), "v"(1) : "memory");
+      if (lane < 4) asm volatile("ds_add_u64 %0, %1" : : "v"(pkb_lds_off(&sm.tot[set][npar][lane])), "v"(mine) : "memory");
+      if (lane == 0) asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(old) : "v"(pkb_lds_off(&sm.cnt[set][npar])), "v"(1) : "memory");
       old = __builtin_amdgcn_readfirstlane(old);
       if (old == WPB - 1)
       {
+        long long t = 0;
         if (lane < 4)
         {
-          long long t;
-          asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(t) : "v"(pkb_lds_off(&sm.tot[par][lane])) : "memory");
-          asm volatile("ds_write_b64 %0, %1" : : "v"(pkb_lds_off(&sm.tot[par][lane])), "v"(0LL) : "memory");
-          PShard *sh = vb + (size_t)((r + 1) & (PRK_NSETS - 1)) * NSHARD + shard;
-          __hip_atomic_fetch_add(&sh->word[lane], (unsigned long long)t + PRK_BIAS + PRK_TICKET, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(t) : "v"(pkb_lds_off(&sm.tot[set][npar][lane])) : "memory");
+          if (set == 1)
+          {
+            asm volatile("ds_write_b64 %0, %1" : : "v"(pkb_lds_off(&sm.tot[set][npar][lane])), "v"(0LL) : "memory");
+            PShard *sh = vb + (size_t)((r + 1) & (PRK_NSETS - 1)) * NSHARD + shard;
+            __hip_atomic_fetch_add(&sh->word[lane], (unsigned long long)t + PRK_BIAS + PRK_TICKET, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
         }
-        if (lane == 0) asm volatile("ds_write_b32 %0, %1" : : "v"(pkb_lds_off(&sm.cnt[par])), "v"(0) : "memory");
+        if (set == 1 && lane == 0) asm volatile("ds_write_b32 %0, %1" : : "v"(pkb_lds_off(&sm.cnt[set][npar])), "v"(0) : "memory");
+        if constexpr (SPEC)
+        {
+          const long long q0 = prk_readlane_u64((unsigned long long)t, 0), q1 = prk_readlane_u64((unsigned long long)t, 1);
+          const long long q2 = prk_readlane_u64((unsigned long long)t, 2), q3 = prk_readlane_u64((unsigned long long)t, 3);
+          long long c = 0;
+          int g = 0;
+          if (q0 > c) { c = q0; g = 0; }
+          if (q1 > c) { c = q1; g = 1; }
+          if (q2 > c) { c = q2; g = 2; }
+          if (q3 > c) { c = q3; g = 3; }
+          const int informative = !(q0 == q1 && q1 == q2 && q2 == q3) && a.spec_on;
+          if (lane == 0) sm.word[par][1] = (informative << 8) | g;
+        }
       }
     };
 
-    // ---- LEAN?  (ramx_kernels_resident.h: no lane can contribute more than its cap to the vote of row r+1 or set a record in
-    // row r.)  prevBest = best cell of row r-1, high = record after row r-1.  Up to leader_max lanes that fail the test
-    // (`leaders`) do not keep the wave from the LEAN row: pkb_leader_rows computes what it skipped for them.
-    const int jhi = bdy - r;
-    const int capfloor = (high + a.cap) > 0 ? (high + a.cap) : 0;
-    bool lean = false, early = false;
-    unsigned long long leaders = 0;
-    if (live && a.lean_p >= 0)
+    // ---- row r: on the guess first (if this workgroup has one), on the winner otherwise / afterwards -----------------------
+    int Rb[SPEC ? NP : 1], high_b = 0, pos_b = 0, prev_b = 0, pbase_b = 0;       // row r-1: m in registers, e in LDS (sm.eb)
+    int *myEb = sm.eb + (SPEC ? threadIdx.x * NP : 0);
+    bool pass_spec = false;
+    int wsel = 0;
+    if (spec)
     {
-      const unsigned long long keep = __ballot((n < a.Nx) && !((prevBest + 2 * a.lean_p <= capfloor) && (prevBest + a.lean_p <= high)));
-      if (keep == 0) { lean = true; early = true; }
-      else if (__popcll(keep) <= a.leader_max) { lean = true; leaders = keep; }
+      if constexpr (SPEC)
+      {
+#ifndef PKB_PROBE_NO_BACKUP      // timing probe (wrong results after a wrong guess)
+        static_for([&](auto kc) __attribute__((always_inline)) { constexpr int k = decltype(kc)::value; Rb[k] = R[k]; myEb[k] = E[k]; }, std::make_integer_sequence<int, NP>{});
+#else
+        Rb[0] = R[0];
+#endif
+        high_b = high; pos_b = pos; prev_b = prevBest; pbase_b = pbase;
+      }
+      pass_spec = true;
+      wsel = guess;
+      if (a.test_wrong_every > 0 && (r % a.test_wrong_every) == 0) wsel = (guess + 1) & 3;      // test hook: a deliberately wrong guess
     }
-    if (!live) early = true;
-    if (early && !last_col)
+    else
     {
-      // this wave's contribution to row r+1 is the sum of its caps whatever the row holds (ram_extend.c:1042, 1052-1062)
-      const long long t = wave_sum_nonneg31((live && n < a.Nx) ? capfloor : 0);
-      arrive(t, t, t, t);
+      if (!decide()) break;
+      wsel = besta;
     }
-    PKB_TICK(3);                 // early arrival
+    bool confirmed_arrival = false;        // this wave's sums of row r+1 (from the confirmed row r) have joined set 1
+    bool gave_up = false;                  // (wave-uniform, unlike `failed`, which the vote wave's lanes set one by one)
+    for (;;)
+    {
+      const int set = pass_spec ? 0 : 1;
+      // ---- LEAN?  (ramx_kernels_resident.h: no lane can contribute more than its cap to the vote of row r+1 or set a record in
+      // row r.)  prevBest = best cell of row r-1, high = record after row r-1.  Up to leader_max lanes that fail the test
+      // (`leaders`) do not keep the wave from the LEAN row: pkb_leader_rows computes what it skipped for them.
+      const int jhi = bdy - r;
+      const int capfloor = (high + a.cap) > 0 ? (high + a.cap) : 0;
+      bool lean = false, early = false;
+      unsigned long long leaders = 0;
+      if (live && a.lean_p >= 0)
+      {
+        const unsigned long long keep = __ballot((n < a.Nx) && !((prevBest + 2 * a.lean_p <= capfloor) && (prevBest + a.lean_p <= high)));
+        if (keep == 0) { lean = true; early = true; }
+        else if (__popcll(keep) <= a.leader_max) { lean = true; leaders = keep; }
+      }
+      if (!live) early = true;
+      const bool send = pass_spec || !last_col;
+      if (early && send)
+      {
+        // this wave's contribution to row r+1 is the sum of its caps whatever the row holds (ram_extend.c:1042, 1052-1062)
+        const long long t = wave_sum_nonneg31((live && n < a.Nx) ? capfloor : 0);
+        arrive(set, t, t, t, t);
+      }
+      PKB_TICK(3);                 // early arrival
 
-    // ---- the band ----------------------------------------------------------------------------
-    int contrib[4] = { 0, 0, 0, 0 };       // each in [0, 2^31): clamped at 0 below, capped from below by high + cap
-    if (live)
-    {
-      const int ph4 = 4 * ((r + 8) & 7);
-      int best, kg[NG], bA[4], maxE;
-      if (lean)
+      // ---- the band ----------------------------------------------------------------------------
+      int contrib[4] = { 0, 0, 0, 0 };       // each in [0, 2^31): clamped at 0 below, capped from below by high + cap
+      if (live)
       {
-        switch (besta)
+        const int ph4 = 4 * ((r + 8) & 7);
+        int best, kg[NG], bA[4], maxE;
+        if (lean) pkb_band<W, BLOCK, false>(go2, ge2, sm.pt, wsel, ph4, w, R, E, best, kg, bA, maxE);
+        else pkb_band<W, BLOCK, true>(go2, ge2, sm.pt, wsel, ph4, w, R, E, best, kg, bA, maxE);
+        int rel, jbest = 0, bestA[4] = { NEG, NEG, NEG, NEG };
+        if (lean) rel = pkb_hmax(best);
+        else
         {
-          case 0: pkb_band<W, BLOCK, 0, false>(go2, ge2, sm.pt, ph4, w, R, E, best, kg, bA, maxE); break;
-          case 1: pkb_band<W, BLOCK, 1, false>(go2, ge2, sm.pt, ph4, w, R, E, best, kg, bA, maxE); break;
-          case 2: pkb_band<W, BLOCK, 2, false>(go2, ge2, sm.pt, ph4, w, R, E, best, kg, bA, maxE); break;
-          default: pkb_band<W, BLOCK, 3, false>(go2, ge2, sm.pt, ph4, w, R, E, best, kg, bA, maxE); break;
-        }
-        lean_rows++;
-      }
-      else
-      {
-        switch (besta)
-        {
-          case 0: pkb_band<W, BLOCK, 0, true>(go2, ge2, sm.pt, ph4, w, R, E, best, kg, bA, maxE); break;
-          case 1: pkb_band<W, BLOCK, 1, true>(go2, ge2, sm.pt, ph4, w, R, E, best, kg, bA, maxE); break;
-          case 2: pkb_band<W, BLOCK, 2, true>(go2, ge2, sm.pt, ph4, w, R, E, best, kg, bA, maxE); break;
-          default: pkb_band<W, BLOCK, 3, true>(go2, ge2, sm.pt, ph4, w, R, E, best, kg, bA, maxE); break;
-        }
-        full_rows++;
-      }
-      int rel, jbest = 0, bestA[4] = { NEG, NEG, NEG, NEG };
-      if (lean) rel = pkb_hmax(best);
-      else
-      {
-        // best cell: highest value, lowest group on ties (inside a group the key already prefers the lowest cell)
-        int bkey = kg[NG - 1], bg = NG - 1;
-        rel = kg[NG - 1] >> 16;
+          // best cell: highest value, lowest group on ties (inside a group the key already prefers the lowest cell)
+          int bkey = kg[NG - 1], bg = NG - 1;
+          rel = kg[NG - 1] >> 16;
 #pragma unroll
-        for (int g = NG - 2; g >= 0; g--)
-        {
-          const int v = kg[g] >> 16;
-          const bool take = v >= rel;
-          rel = take ? v : rel;
-          bkey = take ? kg[g] : bkey;
-          bg = take ? g : bg;
-        }
-        jbest = 32 * bg + 31 - (bkey & 31);
-        const int mE = pkb_hmax(maxE);
+          for (int g = NG - 2; g >= 0; g--)
+          {
+            const int v = kg[g] >> 16;
+            const bool take = v >= rel;
+            rel = take ? v : rel;
+            bkey = take ? kg[g] : bkey;
+            bg = take ? g : bg;
+          }
+          jbest = 32 * bg + 31 - (bkey & 31);
+          const int mE = pkb_hmax(maxE);
+          int rot[4];
 #pragma unroll
-        for (int c = 0; c < 4; c++) bestA[c] = jhi < 1 ? NEG : pbase + imax(pkb_hmax(bA[c]), mE);
-      }
-      const int bestF = jhi < 0 ? SENT : pbase + rel;      // a flank that has run out: every cell holds the sentinel (bnw_extend.c:990-1002)
-      for (unsigned long long rest = leaders; rest != 0; rest &= rest - 1)
-        pkb_leader_rows<W, BLOCK>(sm.pt, sm.lead[wave], (r + 8) & 7, __builtin_ctzll(rest), pbase, jhi, bestF, w, R, E, bestA, jbest);
-      // the base follows the row's best cell (every 16th row, when some lane's has moved far enough)
-      if ((r & 15) == 15 && __any(jhi >= 0 && (rel > a.rebase || rel < -a.rebase)))
-      {
-        const int mv = jhi >= 0 ? rel : 0;
-        const int bb = pk_two(mv);
-        static_for([&](auto kc) __attribute__((always_inline)) { constexpr int k = decltype(kc)::value; R[k] = pkb_sub_sat(R[k], bb); E[k] = pkb_sub_sat(E[k], bb); },
-                   std::make_integer_sequence<int, NP>{});
-        pbase += mv;
-      }
-      prevBest = bestF;
-      if (bestF > high) { high = bestF; pos = r + jbest - W; }   // ram_extend.c:1140-1150
-      if (new_max) { thigh = high; tpos = pos; }                  // :1203-1207
-      if (n < a.Nx)
-      {
-        const int capv = high + a.cap;
+          for (int i = 0; i < 4; i++) rot[i] = jhi < 1 ? NEG : pbase + imax(pkb_hmax(bA[i]), mE);
+          // bA[i] belongs to candidate (wsel + i) mod 4
 #pragma unroll
-        for (int c = 0; c < 4; c++)
-        {
-          const int b = bestA[c] < 0 ? 0 : bestA[c];
-          contrib[c] = (b >= capv) ? b : capv;
+          for (int c = 0; c < 4; c++)
+          {
+            const int i = (c - wsel) & 3;
+            bestA[c] = i == 0 ? rot[0] : i == 1 ? rot[1] : i == 2 ? rot[2] : rot[3];
+          }
         }
+        const int bestF = jhi < 0 ? SENT : pbase + rel;      // a flank that has run out: every cell holds the sentinel (bnw_extend.c:990-1002)
+        for (unsigned long long rest = leaders; rest != 0; rest &= rest - 1)
+          pkb_leader_rows<W, BLOCK>(sm.pt, sm.lead[wave], (r + 8) & 7, __builtin_ctzll(rest), pbase, jhi, bestF, w, R, E, bestA, jbest);
+        // the base follows the row's best cell (every 16th row, when some lane's has moved far enough)
+        if ((r & 15) == 15 && __any(jhi >= 0 && (rel > a.rebase || rel < -a.rebase)))
+        {
+          const int mv = jhi >= 0 ? rel : 0;
+          const int bb = pk_two(mv);
+          static_for([&](auto kc) __attribute__((always_inline)) { constexpr int k = decltype(kc)::value; R[k] = pkb_sub_sat(R[k], bb); E[k] = pkb_sub_sat(E[k], bb); },
+                     std::make_integer_sequence<int, NP>{});
+          pbase += mv;
+        }
+        prevBest = bestF;
+        if (bestF > high) { high = bestF; pos = r + jbest - W; }   // ram_extend.c:1140-1150
+        if (n < a.Nx)
+        {
+          const int capv = high + a.cap;
+#pragma unroll
+          for (int c = 0; c < 4; c++)
+          {
+            const int b = bestA[c] < 0 ? 0 : bestA[c];
+            contrib[c] = (b >= capv) ? b : capv;
+          }
+        }
+        if (!pass_spec) { if (lean) lean_rows++; else full_rows++; }
       }
+      PKB_TICK(2);                 // band done
+      if (!early && send)
+      {
+#ifndef PKB_PROBE_NO_REDUCE      // timing probe (wrong results)
+        const long long t0 = wave_sum_nonneg31(contrib[0]), t1 = wave_sum_nonneg31(contrib[1]);
+        const long long t2 = wave_sum_nonneg31(contrib[2]), t3 = wave_sum_nonneg31(contrib[3]);
+#else
+        const long long t0 = __builtin_amdgcn_readfirstlane(contrib[0]), t1 = __builtin_amdgcn_readfirstlane(contrib[1]);
+        const long long t2 = __builtin_amdgcn_readfirstlane(contrib[2]), t3 = __builtin_amdgcn_readfirstlane(contrib[3]);
+#endif
+        arrive(set, t0, t1, t2, t3);
+      }
+      PKB_TICK(4);                 // late arrival
+      if (!pass_spec) { confirmed_arrival = send; break; }
+      // ---- the row was computed on the guess: what does the vote say? -------------------------------------------------
+      if (!decide()) { gave_up = true; break; }
+      const bool right = besta == wsel;
+      if (wave == 0)
+      {
+        // the speculative totals are complete (every wave arrived before the barrier): send them if they stand, clear them
+        if (lane < 4)
+        {
+          long long t;
+          asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(t) : "v"(pkb_lds_off(&sm.tot[0][npar][lane])) : "memory");
+          asm volatile("ds_write_b64 %0, %1" : : "v"(pkb_lds_off(&sm.tot[0][npar][lane])), "v"(0LL) : "memory");
+          if (right && !last_col)
+          {
+            PShard *sh = vb + (size_t)((r + 1) & (PRK_NSETS - 1)) * NSHARD + shard;
+            __hip_atomic_fetch_add(&sh->word[lane], (unsigned long long)t + PRK_BIAS + PRK_TICKET, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+        if (lane == 0) asm volatile("ds_write_b32 %0, %1" : : "v"(pkb_lds_off(&sm.cnt[0][npar])), "v"(0) : "memory");
+      }
+      if (right) break;
+      // guessed wrong: back to row r-1 and the records behind it
+      if constexpr (SPEC)
+      {
+        static_for([&](auto kc) __attribute__((always_inline)) { constexpr int k = decltype(kc)::value; R[k] = Rb[k]; E[k] = myEb[k]; }, std::make_integer_sequence<int, NP>{});
+        high = high_b; pos = pos_b; prevBest = prev_b; pbase = pbase_b;
+      }
+      wrong_rows++;
+      pass_spec = false;
+      wsel = besta;
     }
-    PKB_TICK(2);                 // band done
+    if (gave_up) break;
+#ifndef PKB_PROBE_NO_TRIM
+    if (new_max && live)                                        // ram_extend.c:1203-1207 (the confirmed records)
+#else
+    if (new_max && live && r < 0)
+#endif
+    {
+      int nn = n;
+      asm volatile("" : "+v"(nn));
+      a.trim[nn] = make_int2(high, pos);
+    }
     if (last_col) break;
-    if (!early)
+    // next column: the guess its totals gave.  After a confirmed round the last arriver wrote it just now: one more barrier makes
+    // it (and the cleared totals) everybody's; after a guess that stood, the barrier of decide() has done so already
+    if constexpr (SPEC)
     {
-      const long long t0 = wave_sum_nonneg31(contrib[0]), t1 = wave_sum_nonneg31(contrib[1]);
-      const long long t2 = wave_sum_nonneg31(contrib[2]), t3 = wave_sum_nonneg31(contrib[3]);
-      arrive(t0, t1, t2, t3);
+      if (confirmed_arrival)
+      {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        int gw;
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(gw) : "v"(pkb_lds_off(&sm.word[par][1])) : "memory");
+        next_guess = __builtin_amdgcn_readfirstlane(gw);
+      }
+      spec = next_guess >> 8; guess = next_guess & 3;
     }
-    PKB_TICK(4);                 // late arrival
   }
 #ifdef RAMX_PRK_TIMING
   if (a.dbg != NULL && (threadIdx.x & 63) == 0)
@@ -607,10 +775,14 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 256) void ramx_packed_kernel(const P
   if (live && rows_done > a.r0)
   {
     // the rows are those of row rl = rows_done - 1; cells beyond the flank's end carry the reference's fill (bnw_extend.c:990-1002)
-    const int rl = rows_done - 1, jh = bdy - rl;
+    int bz = bdy;
+    asm volatile("" : "+v"(bz));
+    const int rl = rows_done - 1, jh = bz - rl;
     const int edge = rl < W ? a.go + (rl + 1) * a.ge : SENT;
-    int4 *S3 = S;
-    asm volatile("" : "+v"(S3));
+    // (recomputed from an opaque copy of the lane index: the pointer would otherwise stay in two registers through the whole loop)
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    int4 *S3 = a.S + (size_t)(blockIdx.x * WPB + (tid >> 6)) * Q * 64 + (tid & 63);
     auto val = [&](int half, int j, bool is_e) __attribute__((always_inline)) -> int
     {
       if (j > jh) { const int f = j < W ? edge : SENT; return is_e ? f + a.ge : f; }
@@ -627,13 +799,13 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 256) void ramx_packed_kernel(const P
       }
       else S3[(size_t)q * 64] = make_int4(m0, e0, high, pos);
     }, std::make_integer_sequence<int, Q>{});
-    a.trim[n] = make_int2(thigh, tpos);
   }
   if (blockIdx.x == 0 && threadIdx.x == 0)
   {
     RamxCtl o;
-    o.max_ext = max_ext; o.max_row = max_row; o.stopped = stopped; o.rows_done = rows_done; o.overflow = ovf;
-    o.besta = lean_rows;           // reported as ramx_run_info.packed_rows: LEAN rows of the first wave
+    o.max_ext = ((long long)sm.st[1] << 32) | (long long)(unsigned)sm.st[0]; o.max_row = sm.st[2]; o.stopped = stopped; o.rows_done = rows_done;
+    o.overflow = sm.st[3];
+    o.besta = lean_rows | (wrong_rows << 16);      // reported: LEAN rows of the first wave, rows it computed twice after a wrong guess
     o.pad = failed;
     *a.ctl_out = o;
   }

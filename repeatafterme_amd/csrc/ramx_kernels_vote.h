@@ -209,3 +209,11 @@ __device__ __forceinline__ unsigned pk_byte_shl(unsigned A)   // ((A >> 8*BYTE) 
   else asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(d) : "n"(SH), "v"(A));
   return d;
 }
+template <int HALF, int SH>
+__device__ __forceinline__ unsigned pk_word_shl(unsigned A)   // ((A >> 16*HALF) & 0xffff) << SH
+{
+  unsigned d;
+  if (HALF == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(d) : "n"(SH), "v"(A));
+  else asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(d) : "n"(SH), "v"(A));
+  return d;
+}

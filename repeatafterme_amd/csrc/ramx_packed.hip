@@ -49,8 +49,11 @@ static int pk_shape(int tiles, int *block, int *blocks)
   // one wave per SIMD while the flank set allows it, two above
   if ((rc = pk_capacity<W, 256>(&cap)) != RAMX_OK) return rc;
   if ((tiles + 3) / 4 <= cap) { *block = 256; *blocks = (tiles + 3) / 4; return RAMX_OK; }
-  if ((rc = pk_capacity<W, 512>(&cap)) != RAMX_OK) return rc;
-  if ((tiles + 7) / 8 <= cap) { *block = 512; *blocks = (tiles + 7) / 8; }
+  if constexpr (W <= 40)       // W = 80: 162 row registers leave no room for a second wave per SIMD (it would run from scratch memory)
+  {
+    if ((rc = pk_capacity<W, 512>(&cap)) != RAMX_OK) return rc;
+    if ((tiles + 7) / 8 <= cap) { *block = 512; *blocks = (tiles + 7) / 8; }
+  }
   return RAMX_OK;
 }
 
@@ -71,7 +74,11 @@ template <int W>
 static int pk_launch(hipStream_t st, int block, int blocks, const PKArgs &a)
 {
   if (block == 256) hipLaunchKernelGGL((ramx_packed_kernel<W, 256>), dim3(blocks), dim3(256), 0, st, a);
-  else if (block == 512) hipLaunchKernelGGL((ramx_packed_kernel<W, 512>), dim3(blocks), dim3(512), 0, st, a);
+  else if (block == 512)
+  {
+    if constexpr (W <= 40) hipLaunchKernelGGL((ramx_packed_kernel<W, 512>), dim3(blocks), dim3(512), 0, st, a);
+    else return RAMX_ERR_ARG;
+  }
   else return RAMX_ERR_ARG;
   return hipGetLastError() == hipSuccess ? RAMX_OK : RAMX_ERR_HIP;
 }

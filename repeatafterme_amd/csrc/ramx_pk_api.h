@@ -31,6 +31,8 @@ struct PKArgs
   int leader_max;               // a wave with at most this many lanes that fail the LEAN test runs LEAN + pkb_leader_rows (0: off)
   int spread;                   // an in-bounds cell lies at most this far below its row's best cell (entry check)
   int rebase;                   // |best cell - base| that moves the base (looked at every 16th row)
+  int spec_on;                  // 1: a workgroup computes a row on its own argmax before the vote is known (RAMX_NO_PK_SPEC=1: 0)
+  int test_wrong_every;         // test hook (RAMX_TEST_PK_WRONG_EVERY=n): every n-th guess is replaced by another base; 0 = off
   unsigned long long *dbg;      // -DRAMX_PRK_TIMING builds only: [wave][8] phase sums in 10 ns ticks
 };
 
