@@ -108,7 +108,11 @@ __device__ __forceinline__ void pkb_tabs_init(PkTabs &pt, const int (&tab)[RAMX_
 {
   for (int i = threadIdx.x; i < 256; i += BLOCK)
   {
-    const int lo = i & 15, hi = i >> 4;
+    // entry (hi, lo) sits at index hi << 4 | (lo ^ ((hi & 3) << 2)): the LDS bank of a lookup is its index's low bits, and with
+    // the plain index two lanes whose low classes agree and whose high classes differ meet in one bank (58 % of the LDS cycles
+    // of the first version were bank conflicts); this way the sixteen pairs of A C G T sit in sixteen different banks.  The row
+    // forms the same index from the base word: A ^ ((A >> 2) & 0x0c0c0c0c), three instructions per four pairs.
+    const int hi = i >> 4, lo = (i & 15) ^ ((hi & 3) << 2);
     int q[4];
 #pragma unroll
     for (int c = 0; c < 4; c++)
@@ -123,6 +127,10 @@ __device__ __forceinline__ void pkb_tabs_init(PkTabs &pt, const int (&tab)[RAMX_
   }
 }
 
+// (A hand-ordered version of this row -- every pair of cells one asm block in which no instruction follows its producer, the
+// candidate terms of the pair before between the links of the insertion chain -- removed the 230 s_nop the compiler puts
+// behind packed / op_sel producers (1,180 -> 1,050 instructions per FULL row) and was SLOWER: 7.65 against 7.25 us per column in
+// the aligned phase, profiles/r04_notes.md.  With two waves per SIMD the wait states are the other wave's issue slots.)
 // One row on the packed representation.  wsel: the winner (wave-uniform; part of the table index).  ph4: 4 x the nibble phase of
 // step 0 in w[0].  FULL: kg[] = best cell keys per group of 32 cells, bA[i] = running maximum (packed) of candidate
 // (wsel + i) mod 4, maxE = max e (packed); LEAN: best = the row's best value (packed halves).
@@ -148,7 +156,8 @@ __device__ __forceinline__ void pkb_band(const int go2, const int ge2, const PkT
     constexpr int k = decltype(kc)::value, qi = decltype(qc)::value;
     if constexpr ((k & 3) == 0)
     {
-      const unsigned A = __builtin_amdgcn_alignbit(w[(k >> 2) + 1], w[k >> 2], ph4);
+      unsigned A = __builtin_amdgcn_alignbit(w[(k >> 2) + 1], w[k >> 2], ph4);
+      A ^= (A >> 2) & 0x0c0c0c0cu;                    // bank swizzle of the table index (pkb_tabs_init)
       Alo = __builtin_amdgcn_perm(wrep, A, 0x04010400u);
       Ahi = __builtin_amdgcn_perm(wrep, A, 0x04030402u);
     }
@@ -627,6 +636,10 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 256) void ramx_packed_kernel(const P
         arrive(set, t, t, t, t);
       }
       PKB_TICK(3);                 // early arrival
+      // a wave whose sums come after its row (FULL, or LEAN with leaders) is what the workgroup's ticket waits for: it goes first
+      // on its SIMD (behind the end of the alignment that is the one wave holding the leader flank, and the whole device waits
+      // for its workgroup)
+      if (!early) __builtin_amdgcn_s_setprio(2);
 
       // ---- the band ----------------------------------------------------------------------------
       int contrib[4] = { 0, 0, 0, 0 };       // each in [0, 2^31): clamped at 0 below, capped from below by high + cap
@@ -704,6 +717,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 256) void ramx_packed_kernel(const P
         arrive(set, t0, t1, t2, t3);
       }
       PKB_TICK(4);                 // late arrival
+      __builtin_amdgcn_s_setprio(0);
       if (!pass_spec) { confirmed_arrival = send; break; }
       // ---- the row was computed on the guess: what does the vote say? -------------------------------------------------
       if (!decide()) { gave_up = true; break; }
