@@ -838,6 +838,18 @@ static int prk_run(ramx_dev *d, const KArgs &a, int L, bool *used)
     }
     fprintf(stderr, "\n");
     {
+      // the workgroup everybody waits for: the one whose vote wave waits least for the vote
+      int gb = 0;
+      for (int b = 1; b < blocks; b++) if (h[(size_t)b * wpb * 8 + 0] < h[(size_t)gb * wpb * 8 + 0]) gb = b;
+      fprintf(stderr, "PRK_TIMING workgroup %d (shortest vote wait), per wave: wait vote | barrier | band | early | late | top\n", gb);
+      for (int wv = 0; wv < wpb; wv++)
+      {
+        const unsigned long long *q = h + ((size_t)gb * wpb + wv) * 8;
+        fprintf(stderr, "PRK_TIMING   w%d %7.0f %7.0f %7.0f %7.0f %7.0f %7.0f   rows full %llu lean %llu\n", wv, 10.0 * q[0] / L, 10.0 * q[1] / L, 10.0 * q[2] / L,
+                10.0 * q[3] / L, 10.0 * q[4] / L, 10.0 * q[5] / L, q[6], q[7]);
+      }
+    }
+    {
       // second half of the run: waves that were kept from the LEAN band, and by how many lanes
       const double half = L - L / 2;
       size_t never = 0, always = 0, wg_any = 0;

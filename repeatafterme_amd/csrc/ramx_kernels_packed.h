@@ -291,7 +291,13 @@ __device__ __forceinline__ void pkb_leader_rows(const PkTabs &pt, int *scr /* [2
 }
 
 #ifdef RAMX_PRK_TIMING
-#define PKB_TICK(k) do { const unsigned long long t_ = wall_clock64(); tsum[k] += t_ - tlast; tlast = t_; } while (0)
+// (-DRAMX_PRK_TIMING_TAIL: only the second half of the columns is accounted)
+#ifdef RAMX_PRK_TIMING_TAIL
+#define PKB_TICK_ON (2 * r >= a.L)
+#else
+#define PKB_TICK_ON true
+#endif
+#define PKB_TICK(k) do { const unsigned long long t_ = wall_clock64(); if (PKB_TICK_ON) tsum[k] += t_ - tlast; tlast = t_; } while (0)
 #else
 #define PKB_TICK(k) do { } while (0)
 #endif
@@ -639,7 +645,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 256) void ramx_packed_kernel(const P
       // a wave whose sums come after its row (FULL, or LEAN with leaders) is what the workgroup's ticket waits for: it goes first
       // on its SIMD (behind the end of the alignment that is the one wave holding the leader flank, and the whole device waits
       // for its workgroup)
-      if (!early) __builtin_amdgcn_s_setprio(2);
+      if (__builtin_amdgcn_readfirstlane(early ? 1 : 0) == 0) __builtin_amdgcn_s_setprio(2);     // (a scalar branch: under an exec mask it would run in every wave)
 
       // ---- the band ----------------------------------------------------------------------------
       int contrib[4] = { 0, 0, 0, 0 };       // each in [0, 2^31): clamped at 0 below, capped from below by high + cap
