@@ -41,6 +41,19 @@ N_SIMD, CLOCK_GHZ, GUIDE_ISSUE_CYCLES = 1024, 2.4, 2.0
 VALU_PEAK_GINST = N_SIMD * CLOCK_GHZ / GUIDE_ISSUE_CYCLES
 
 
+def device_source_sha16() -> str:
+    """sha256 (first 16 hex digits) over the device sources of libramx: what ties a PMC summary under profiles/ to the kernels
+    that are being timed (the library itself is rebuilt on every box; the sources travel)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "repeatafterme_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "ramx_kernels_*.h")) + glob.glob(os.path.join(d, "ramx_*_api.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def algorithmic_bytes_per_flank_column(W: int) -> float:
     """read prev row + write curr row + 1/4 B base + 16 B (high,pos)."""
     B = 2 * W + 1
@@ -275,7 +288,8 @@ def main():
     lanes = infos[0].lanes_per_flank if infos else 1
     if persistent:
         # ONE launch per step processes N flanks x L columns; its duration is the event-timed loop
-        kernel = f"ramx_persistent_kernel<{W}>" if lanes == 1 else f"ramx_cp_kernel<{W},{lanes},device-wide>"
+        packed = bool(infos and infos[0].packed_rows > 0)
+        kernel = (f"ramx_packed_kernel<{W}>" if packed else f"ramx_persistent_kernel<{W}>") if lanes == 1 else f"ramx_cp_kernel<{W},{lanes},device-wide>"
         n_launch = len(infos)
         kavg_ms = loop_ms / n_launch
         abytes = per_col_bytes * rows / n_launch
@@ -299,7 +313,10 @@ def main():
             doc = json.load(open(pmc))
             ent = doc.get("persistent" if persistent else "column", {})
             cfg = doc.get("config", {"flanks": 100000, "bandwidth": 40})
-            if cfg.get("flanks") == N and cfg.get("bandwidth") == W and lanes == 1 and cfg.get("L", L) == L:
+            # the counters describe ONE build: the summary names the device sources it was collected on
+            if doc.get("device_source_sha16") != device_source_sha16():
+                pmc_source = "profiles/pmc_summary.json is from other device sources (%s): not used" % doc.get("device_source_sha16")
+            elif cfg.get("flanks") == N and cfg.get("bandwidth") == W and lanes == 1 and cfg.get("L", L) == L:
                 per_col = ent.get("hbm_bytes_per_column")
                 fit = doc.get("persistent_fit")
                 if persistent and fit:
@@ -355,8 +372,8 @@ def main():
         # a register-resident launch with no instruction count for THIS configuration: the rows never move, so there is no
         # honest byte or instruction rate to quote -- say what was measured (time per column) and nothing else
         roof = {"bound": "latency" if lanes > 1 else "valu", "achieved": None, "peak": VALU_PEAK_GINST, "unit": "G wave64-inst/s",
-                "frac": None, "note": "no PMC instruction count collected for this (flanks, bandwidth, lanes per flank, ranks); "
-                                      "us_per_column is the measured quantity"}
+                "frac": None, "note": (pmc_source or "no PMC instruction count collected for this (flanks, bandwidth, lanes per flank, ranks)")
+                                      + "; us_per_column is the measured quantity"}
     else:
         # streaming kernel: the rows really are read once and written once per column
         roof = {"bound": "hbm", "achieved": (traffic / (kavg_ms * 1e-3) / 1e9) if (traffic and kavg_ms > 0) else alg_gbps,
@@ -372,6 +389,27 @@ def main():
                                   "algorithmic rate may exceed the 8 TB/s peak; `traffic` is what the PMC counters saw")
                                  if persistent else "streaming kernel: rows read once and written once per column"}})
 
+    # ---- outside the timed region: which regime was measured.  With K = 1,500 shared columns and stopafter = L the timed launch
+    # is two regimes: the ALIGNED phase (every flank still aligns: full rows -- the regime of every real run, which stops ~100
+    # columns behind the end of the alignment) and the CAPPED TAIL (flanks at their caps: LEAN rows, exact and digest-checked, but
+    # cheaper).  One more launch over the first K columns separates them.
+    phases = None
+    if world == 1 and persistent and lanes == 1 and L > 1500 and args.ragged == 0:
+        K = 1500
+        pk = ExtendParams(bandwidth=W, cappenalty=p.cappenalty, minimprovement=p.minimprovement, L=K, when_to_stop=K, l=1,
+                          gapopen=go, gapextn=ge, matrix=mat, matrix_name="14p43g")
+        dev.begin_direction(flanks, pk)
+        dev.run_direction()
+        best_k = min(dev.run_direction().loop_ms for _ in range(3))
+        dev.begin_direction(flanks, p)                      # (the timed configuration again, for whatever follows)
+        full_ms = loop_ms / n_launch
+        i0 = infos[0]
+        phases = {"aligned_columns": K, "aligned_us_per_column": best_k * 1e3 / K,
+                  "tail_columns": L - K, "tail_us_per_column": (full_ms - best_k) * 1e3 / (L - K),
+                  "packed_rows": int(i0.packed_rows), "lean_rows_of_the_first_wave": int(i0.lean_rows),
+                  "rows_computed_twice_after_a_wrong_guess": int(i0.respeculated_rows),
+                  "note": "aligned = a launch over the first 1,500 columns alone (every row FULL); tail = the rest of the timed launch "
+                          "(rows LEAN once the flanks sit at their caps); `value` is the whole launch"}
     # ---- outside the timed region: seam 1 (host buffers in, host results out) on the same set ----------------------
     seam1 = None
     if world == 1 and not args.no_seam1:
@@ -385,6 +423,28 @@ def main():
                  "ms_right": t_r * 1e3, "ms_left": t_l * 1e3, "columns": s_cols, "columns_per_sec": s_cols / (t_r + t_l),
                  "flank_bp_per_sec": (r_right.rows_executed * r_right.n_extendable + r_left.rows_executed * r_left.n_extendable) / (t_r + t_l),
                  "loop_ms_right": r_right.loop_ms, "prep_ms_right": r_right.prep_ms}
+    # ---- ... and a REAL run: the same set with the reference's default -stopafter 100 (what util/extend-stk.pl:365 runs): the
+    # loop stops 100 columns behind the end of the alignment, so prep / download are a large part of the call
+    real_run = None
+    if world == 1 and not args.no_seam1 and args.ragged == 0:
+        from repeatafterme_amd.datamodel import new_master
+        from repeatafterme_amd.extend import extend_alignment
+        pr = ExtendParams(bandwidth=W, cappenalty=p.cappenalty, minimprovement=p.minimprovement, L=L, when_to_stop=100, l=1,
+                          gapopen=go, gapextn=ge, matrix=mat, matrix_name="14p43g")
+        best = None
+        for _ in range(2):
+            c1 = fs.cores.copy(); m1 = new_master(L)
+            t0 = time.perf_counter(); rr = extend_alignment(1, c1, fs.sequence, m1, pr); t_r = time.perf_counter() - t0
+            t0 = time.perf_counter(); rl = extend_alignment(0, c1, fs.sequence, m1, pr); t_l = time.perf_counter() - t0
+            if best is None or t_r + t_l < best[0]:
+                best = (t_r + t_l, t_r, t_l, rr, rl)
+        _, t_r, t_l, rr, rl = best
+        real_run = {"what": "ramx_extend_flat right then left with -stopafter 100 (the wrapper's call): flatten + library on the device + pack + "
+                            "loop + download + write-back, best of 2",
+                    "ms_right": t_r * 1e3, "ms_left": t_l * 1e3, "columns_right": rr.rows_executed, "columns_left": rl.rows_executed,
+                    "ret_right": rr.ret, "loop_ms_right": rr.loop_ms, "prep_ms_right": rr.prep_ms,
+                    "loop_us_per_column": rr.loop_ms * 1e3 / max(rr.rows_executed, 1),
+                    "flank_bp_per_sec_incl_prep_and_download": rr.rows_executed * rr.n_extendable / t_r if t_r > 0 else None}
     # ---- outside the timed region: BASELINE configs[1] (N = 1,000 x L = 2,000: a parity configuration, not the bench
     # line) through seam 1 -- the size class where a column is a latency chain, served by the cell-parallel kernel ------
     cfg1 = None
@@ -435,7 +495,7 @@ def main():
     out = {
         "metric": "flank_bp_aligned_per_sec (extension columns/s x flanks)", "value": value, "unit": "flank-bp/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-        "higher_is_better": True, "scaling": ("strong" if strong else "weak"), "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+        "higher_is_better": True, "scaling": (None if world == 1 else ("strong" if strong else "weak")), "vs_baseline": None, "dtype": "int32", "data": "synthetic",
         "config": {"workload": (f"synthetic N={total_flanks} flanks" + (f" split over {world} GPUs" if strong else (" per GPU" if world > 1 else ""))
                                 + f" x L={L} bp, bandwidth={W}, matrix 14p43g, "
                                 f"K=1500 @14% divergence, right extension, stopafter=L (all L columns)"),
@@ -449,9 +509,12 @@ def main():
         "columns_per_sec": cols / dt,
         "ranks_seen": ranks_seen, "transport": transport,
         "checks": checks,
-        "cell_updates_per_sec": cols / dt * total_flanks * (2 * W + 1) * 4,
+        # ALGORITHMIC: 4 candidate rows per cell and column; LEAN rows evaluate none of them (see `phases`)
+        "algorithmic_cell_updates_per_sec": cols / dt * total_flanks * (2 * W + 1) * 4,
+        "phases": phases,
         "roofline": roof,
         "seam1": seam1,
+        "real_run": real_run,
         "configs1_n1000": cfg1,
         "setup": {"synth_s": t_gen, "upload_pack_s": t_upload},
     }

@@ -389,6 +389,13 @@ static void launch_column_trace(ramx_dev *d, const KArgs &a, bool init = false)
     hipLaunchKernelGGL((ramx_column_kernel<false, true, 256, true>), grid, block, 0, d->stream, a);
 }
 
+// does the vote of a column cross ranks?  (a communicator of ONE rank -- RAMX_COMM_SINGLE=1 at ramx_dev_comm_init -- counts with
+// RAMX_FORCE_COLLECTIVE=1: the RCCL calls of the per-column route then run on a single GPU, tests/test_gpu_sharded.py)
+static bool dev_is_multi(const ramx_dev *d)
+{
+  return (d->comm != NULL && (d->nranks > 1 || getenv("RAMX_FORCE_COLLECTIVE") != NULL)) || d->cb != NULL;
+}
+
 // ---- host-side collective on 4 x int64 in device memory (RCCL, or the test hook) ---------------
 static int host_allreduce_shards(ramx_dev *d, long long *dptr)   // dptr: NSHARD x 4 int64, summed over ranks in place
 {
@@ -685,7 +692,7 @@ static int prk_run(ramx_dev *d, const KArgs &a, int L, bool *used)
 {
   *used = false;
   const int W = a.W;
-  const bool multi = (d->comm != NULL && d->nranks > 1) || d->cb != NULL;
+  const bool multi = dev_is_multi(d);
   int block = 0, blocks = 0, rc;
   bool can = false;
   if ((rc = prk_local_can(d, a, L, multi, &can, &block, &blocks)) != RAMX_OK) return rc;
@@ -1353,7 +1360,7 @@ extern "C" int ramx_dev_run_direction(ramx_dev *d, ramx_run_info *info)
   a.Np = d->Np; a.Nx = d->Nx; a.W = p.bandwidth; a.go = p.gapopen; a.ge = p.gapextn; a.cap = p.cappenalty;
   a.minimp = p.minimprovement; a.when_to_stop = p.when_to_stop;
   memcpy(a.tab, d->tab, sizeof(a.tab));
-  const bool multi = (d->comm != NULL && d->nranks > 1) || d->cb != NULL;
+  const bool multi = dev_is_multi(d);
 
   auto slot = [&](int r) { return d->d_sums + (size_t)(((r % 3) + 3) % 3) * NSHARD * 4; };
   int launches = 0, nsamp = 0, pending = -1, chk = 0, lanes = 1, prk_local_rc = RAMX_OK;
@@ -1832,7 +1839,7 @@ extern "C" int ramx_dev_comm_init(ramx_dev *d, const uint8_t id[128], int rank, 
   if (!d || rank < 0 || rank >= nranks) { ramx_set_error("ramx_dev_comm_init: bad argument"); return RAMX_ERR_ARG; }
   HIPCHK(hipSetDevice(d->ordinal));
   d->rank = rank; d->nranks = nranks;
-  if (nranks == 1) return RAMX_OK;
+  if (nranks == 1 && getenv("RAMX_COMM_SINGLE") == NULL) return RAMX_OK;       // one rank: nothing to exchange (RAMX_COMM_SINGLE=1: make the communicator all the same)
   ncclUniqueId u;
   memcpy(&u, id, 128);
   ncclResult_t r = ncclCommInitRank(&d->comm, nranks, u, rank);

@@ -71,6 +71,13 @@ void ramx_invalidate_library(void)
   g_lib_ptr = NULL; g_lib_len = 0; g_lib_fp = 0; g_lib_trusted = 0; g_bl_n = 0; g_packed_owner = NULL;
 }
 
+/* the loader calls this when it frees a library: a later library that malloc places at the same address must not be taken for the
+ * one the device holds (the packed path is keyed on the owner's pointer alone; the one-byte path also checks length and content) */
+void ramx_forget_library_owner(const struct sequenceLibrary *lib)
+{
+  if (lib != NULL && g_packed_owner == lib) ramx_invalidate_library();
+}
+
 int ramx_preload_library_packed(const struct sequenceLibrary *seqLib, const struct ramx_packed_library *pl)
 {
   if (!seqLib || !pl) { ramx_set_error("ramx_preload_library_packed: bad argument"); return RAMX_ERR_ARG; }
@@ -336,7 +343,35 @@ static int extend_flat_impl(int direction, ramx_flat_cores *c, const int8_t *seq
     vctx.max_ext = 0; vctx.max_row = -1;
     ramx_dev_set_row_verbose(d, verbose_row, &vctx);
   }
-  if (g_trace_file == NULL && !verbose_rows && nx > 0 && nx <= ramx_dev_family_route_max(d, p) && L > 0 && W >= 1 && getenv("RAMX_NO_FAMILY_ROUTE") == NULL)
+  if (g_trace_file == NULL && !verbose_rows && nx == 0 && getenv("RAMX_NO_HOST_EMPTY") == NULL)
+  {
+    /* No core is extendable in this direction: every candidate sum of every row is 0, so the vote (ram_extend.c:1064-1086:
+     * strict > from 0) gives 'A' with a score of 0 in every row and the fit-preferred rule (:1194-1223) runs on scalars.
+     * Nothing to launch (the reference walks its L rows over an empty list the same way). */
+    long long max_ext = 0;
+    int max_row = -1, rows_done = 0, stopped = 0;
+    for (int r = 0; r < L; r++)
+    {
+      long long dist = (long long)max_row - r;
+      if (dist < 0) dist = -dist;
+      if (0 >= max_ext + dist * (long long)p->minimprovement) { max_row = r; max_ext = 0; }
+      int d2 = r - max_row;
+      if (d2 < 0) d2 = -d2;
+      stopped = d2 >= p->when_to_stop;
+      cons[r] = 0;
+      rows_done = r + 1;
+      if (stopped) break;
+    }
+    info->ret = max_row + 1;
+    info->rows_executed = rows_done;
+    info->limit_warning = (stopped && rows_done - 1 == L - 1) ? 1 : 0;
+    info->persistent = 0; info->launches = 0; info->lanes_per_flank = 1; info->n_extendable = 0;
+    info->prep_ms = wall_ms() - t0;
+    th = (int32_t *)malloc(sizeof(int32_t));
+    tp = (int32_t *)malloc(sizeof(int32_t));
+    rc = RAMX_OK;
+  }
+  else if (g_trace_file == NULL && !verbose_rows && nx > 0 && nx <= ramx_dev_family_route_max(d, p) && L > 0 && W >= 1 && getenv("RAMX_NO_FAMILY_ROUTE") == NULL)
   {
     /* a family that fits one workgroup needs no device-wide barrier: run it as a batch of one (block-local vote) */
     const int npad = (nx + 63) & ~63;

@@ -22,6 +22,8 @@ int ramx_dev_family_route_max(ramx_dev *d, const ramx_params *p);
 
 /* the packed twin of a library made by ramx_load_sequence_subset_packed (NULL for any other library) */
 const ramx_packed_library *ramx_packed_of(const struct sequenceLibrary *lib);
+/* a library is about to be freed: the device copy it may own is forgotten (csrc/ramx_extend.c) */
+void ramx_forget_library_owner(const struct sequenceLibrary *lib);
 /* one base of a library of either kind (1 byte per base, or packed) */
 int ramx_lib_code(const struct sequenceLibrary *lib, uint64_t at);
 

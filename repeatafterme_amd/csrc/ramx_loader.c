@@ -785,6 +785,7 @@ void ramx_free_library(struct sequenceLibrary *lib, struct coreAlignment *cores)
   if (lib)
   {
     ramx_packed_library *pl = NULL;
+    ramx_forget_library_owner(lib);
     pthread_mutex_lock(&g_packed_mu);
     for (int i = 0; i < RAMX_MAX_PACKED; i++) if (g_packed[i].lib == lib) { pl = g_packed[i].pl; g_packed[i].lib = NULL; g_packed[i].pl = NULL; }
     __atomic_add_fetch(&g_packed_gen, 1, __ATOMIC_RELEASE);

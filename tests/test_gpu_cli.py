@@ -134,6 +134,64 @@ def test_extend_alignment_struct_entry():
     assert [a.score for a in arr] == c2.score.tolist()
 
 
+def test_packed_library_cache_forgets_a_freed_library(tmp_path):
+    """the device copy of a packed library is keyed on the seqLib pointer.  Load, extend, free, then load ANOTHER genome
+    (malloc hands out the same addresses again) and extend: the second result must be the second genome's -- equal to the
+    oracle on the second library's own bases -- not an extension against the first library's bases still on the device."""
+    import ctypes as C
+    import numpy as np
+    from oracle import pyoracle as po
+    from repeatafterme_amd.loader import _Core, _SeqLib, _Packed, cores_from_list, write_twobit, write_ranges
+    from repeatafterme_amd.scoring import _Scoring
+    from repeatafterme_amd.datamodel import new_master
+    L = _lib.lib()
+    L.ramx_get_matrix.restype = C.POINTER(_Scoring); L.ramx_get_matrix.argtypes = [C.c_char_p]
+    L.ramx_load_sequence_subset_packed.restype = C.POINTER(_SeqLib)
+    L.ramx_load_sequence_subset_packed.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.POINTER(_Core)), C.POINTER(C.c_int),
+                                                   C.c_int, C.POINTER(C.POINTER(_Packed))]
+    L.ramx_packed_decode.argtypes = [C.POINTER(_Packed), C.c_uint64, C.c_uint64, C.c_void_p]
+    L.ramx_free_library.argtypes = [C.POINTER(_SeqLib), C.POINTER(_Core)]
+    L.ramx_extend_alignment.restype = C.c_int
+    L.ramx_extend_alignment.argtypes = [C.c_int, C.POINTER(_Core), C.c_void_p, C.POINTER(_SeqLib), C.c_void_p, C.c_int,
+                                        C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_Scoring), C.c_void_p]
+    sp = L.ramx_get_matrix(b"14p43g")
+    Lx, W = 120, 14
+    L.ramx_set_runtime(0, 30, 1)
+    rets = []
+    for g in (0, 1):
+        # two genomes of the SAME shape (same record names and lengths, same ranges, different bases): the second library's blocks are
+        # of the same sizes as the first one's, which is what makes malloc reuse the addresses
+        rng = np.random.default_rng(900 + g)
+        anc = rng.integers(0, 4, size=260, dtype=np.int8)
+        recs, rows = [], []
+        for i in range(40):
+            fl = anc.copy()
+            sub = rng.random(260) < 0.12
+            fl[sub] = (fl[sub] + rng.integers(1, 4, size=int(sub.sum()))) & 3
+            core = np.array([0, 1, 2, 3, 0, 1, 2, 3, 0, 1, 2, 3], np.int8)
+            recs.append((f"s{i:03d}", np.concatenate((core, fl, rng.integers(0, 4, size=60, dtype=np.int8)))))
+            rows.append((f"s{i:03d}", 0, 12, 0, 1, "+"))
+        tb, rg = str(tmp_path / f"g{g}.2bit"), str(tmp_path / f"g{g}.tsv")
+        write_twobit(tb, recs); write_ranges(rg, rows)
+        head = C.POINTER(_Core)(); n = C.c_int(); pk = C.POINTER(_Packed)()
+        lp = L.ramx_load_sequence_subset_packed(tb.encode(), rg.encode(), C.byref(head), C.byref(n), Lx + W, C.byref(pk))
+        sl = lp.contents
+        seq = np.zeros(int(sl.length), np.int8)
+        _lib.check(L.ramx_packed_decode(pk, 0, sl.length, seq.ctypes.data), "ramx_packed_decode")
+        cores = cores_from_list(head, n.value)
+        m = new_master(Lx)
+        rr = L.ramx_extend_alignment(1, head, None, lp, m.ctypes.data, W, -90, 27, Lx, n.value, sp, None)
+        got = cores_from_list(head, n.value)
+        p = po.Params.named("14p43g", bandwidth=W, L=Lx, when_to_stop=30)
+        c2 = cores.copy(); m2 = new_master(Lx)
+        o1 = po.oracle_extend(1, c2, seq, m2, p)
+        assert rr == o1.ret and np.array_equal(m, m2), f"genome {g}: consensus differs from the oracle on this library's bases"
+        assert np.array_equal(got.right_len, c2.right_len) and np.array_equal(got.score, c2.score), f"genome {g}"
+        rets.append((rr, m.copy()))
+        L.ramx_free_library(lp, head)
+    assert not np.array_equal(rets[0][1], rets[1][1])           # the two genomes really extend differently
+
+
 SEAM1 = os.path.join(ROOT, "oracle", "_ref", "RAMExtend_seam1")
 
 

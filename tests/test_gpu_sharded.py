@@ -21,7 +21,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out, peer=False, W=20, kind="", fail_rank=None, no_cp=False, delay=None):
+def _worker(rank, world, port, out, peer=False, W=20, kind="", fail_rank=None, no_cp=False, delay=None, shape=(333, 150, 100)):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -46,8 +46,8 @@ def _worker(rank, world, port, out, peer=False, W=20, kind="", fail_rank=None, n
         dist.all_gather(outs, buf)
         return np.concatenate([o[:int(s.item())].numpy() for o, s in zip(outs, sizes)])
 
-    fs = synth_family(333, 150, W, K=100, seed=12, both_sides=True, minus_frac=0.3, n_run_frac=0.1)
-    p = po.Params.named("14p43g", bandwidth=W, L=150, when_to_stop=25)
+    fs = synth_family(shape[0], shape[1], W, K=shape[2], seed=12, both_sides=True, minus_frac=0.3, n_run_frac=0.1)
+    p = po.Params.named("14p43g", bandwidth=W, L=shape[1], when_to_stop=25)
     if fail_rank is not None:
         os.environ["RAMX_TEST_FAIL_PRK_RANK"] = str(fail_rank)
     if delay is not None:
@@ -199,3 +199,86 @@ def test_rank_local_failure_after_agreement_falls_back_on_all_ranks():
         assert rets == [(r1.ret, r1.rows_executed), (r0.ret, r0.rows_executed)], rank
         assert np.array_equal(mm, m) and np.array_equal(ll, c.left_len) and np.array_equal(rl, c.right_len)
         assert np.array_equal(sc, c.score)
+
+
+@pytest.mark.parametrize("no_cp", [False, True], ids=["cell-parallel", "lane-per-flank"])
+def test_two_ranks_at_a_real_shard_size(no_cp, monkeypatch):
+    """The mailbox exchange with shards of the size a real multi-GPU run has: 2 x 20,000 flanks (the other tests of this file run
+    333 flanks in ~5 workgroups per rank).  Each rank's launch is 79-90 workgroups; the two launches are co-resident on the box's
+    256 CUs and exchange every column's vote through the mailboxes.  Results = the single-process oracle on all 40,000 flanks."""
+    from oracle import pyoracle as po
+    from repeatafterme_amd.datamodel import new_master
+    from repeatafterme_amd.synth import synth_family
+    if not no_cp:
+        monkeypatch.setenv("RAMX_CP_K", "2")            # 224 flanks per workgroup: 90 workgroups per rank, both ranks resident
+    world, shape, W = 2, (40000, 60, 40), 40
+    out = mp.Manager().dict()
+    mp.spawn(_worker, args=(world, _free_port(), out, True, W, "device", None, no_cp, None, shape), nprocs=world, join=True)
+    fs = synth_family(shape[0], shape[1], W, K=shape[2], seed=12, both_sides=True, minus_frac=0.3, n_run_frac=0.1)
+    p = po.Params.named("14p43g", bandwidth=W, L=shape[1], when_to_stop=25)
+    c = fs.cores.copy(); m = new_master(p.L)
+    r1 = po.oracle_extend(1, c, fs.sequence, m, p); r0 = po.oracle_extend(0, c, fs.sequence, m, p)
+    for rank in range(world):
+        rets, mm, ll, rl, sc, enabled, used, lanes = out[rank]
+        assert enabled and used == 1, (enabled, used)
+        assert (lanes == 1) == no_cp, lanes
+        assert rets == [(r1.ret, r1.rows_executed), (r0.ret, r0.rows_executed)], rank
+        assert np.array_equal(mm, m) and np.array_equal(ll, c.left_len) and np.array_equal(rl, c.right_len)
+        assert np.array_equal(sc, c.score)
+
+
+_RCCL_SCRIPT = r"""
+import os, sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+os.environ["RAMX_COMM_SINGLE"] = "1"          # a communicator of one rank
+os.environ["RAMX_FORCE_COLLECTIVE"] = "1"     # ... whose collectives are used
+os.environ["RAMX_NO_PEER"] = "1"              # the per-column route: one ncclAllReduce per column between the launches
+if {torch_first}:
+    import torch                                 # torch's HIP / RCCL first: libramx binds to them (DESIGN.md section 7)
+import numpy as np
+from oracle import pyoracle as po
+from repeatafterme_amd.datamodel import new_master
+from repeatafterme_amd.device import Device, resolve_flanks
+from repeatafterme_amd.synth import synth_family, writeback_from_trim
+from helpers import to_extend_params
+fs = synth_family(700, 120, 20, K=80, seed=21, both_sides=True, minus_frac=0.3, n_run_frac=0.1)
+p = po.Params.named("14p43g", bandwidth=20, L=120, when_to_stop=25)
+dev = Device(0)
+dev.comm_init(dev.unique_id(), 0, 1)
+assert dev.comm_size() == 1
+dev.load_library(fs.sequence)
+c = fs.cores.copy(); m = new_master(p.L)
+r = po.oracle_extend(1, c, fs.sequence, m, p)
+flanks, idx = resolve_flanks(1, fs.cores, p.bandwidth, p.L)
+dev.begin_direction(flanks, to_extend_params(p))
+info = dev.run_direction()
+cons, th, tp = dev.download()
+assert info.persistent == 0 and info.launches >= info.rows_executed, (info.persistent, info.launches)    # per-column launches
+assert (info.ret, info.rows_executed) == (r.ret, r.rows_executed), (info.ret, r.ret)
+assert np.array_equal(cons[:r.rows_executed], m[p.L + 1:p.L + 1 + r.rows_executed])
+ext, sc = writeback_from_trim(th, tp)
+assert np.array_equal(ext, c.right_len[idx]) and np.array_equal(sc, (c.score - fs.cores.score)[idx])
+loaded = [l.split()[-1] for l in open("/proc/self/maps") if "librccl" in l or "libamdhip64" in l]
+print("RCCL_OK", sorted(set(os.path.basename(x) for x in loaded)), sorted(set(os.path.dirname(x) for x in loaded)))
+dev.close()
+"""
+
+
+@pytest.mark.parametrize("torch_first", [True, False], ids=["torch imported first", "executable order (no torch)"])
+def test_rccl_single_rank_communicator_runs_the_collective_route(torch_first):
+    """The collective north_star names -- one RCCL all-reduce of the column's sums (ram_extend.c:1052-1085 is what it sums) -- on the
+    one GPU a test box has: ramx_comm_unique_id -> ramx_dev_comm_init(d, id, 0, 1) -> ramx_dev_comm_size == 1 -> a direction on
+    the per-column route whose every column goes through ncclAllReduce (csrc/ramx_device.hip host_allreduce_shards), result =
+    oracle.  Once with torch's runtime loaded first and once in the executable's order (no torch in the process: libramx brings
+    /opt/rocm's HIP and RCCL), DESIGN.md section 7's two cases."""
+    import subprocess
+    env = dict(os.environ)
+    for k in ("RAMX_NO_PERSISTENT", "RAMX_NO_CP_DEVICE", "RAMX_CP_K"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-c", _RCCL_SCRIPT.format(root=ROOT, torch_first=torch_first)], capture_output=True, text=True,
+                       env=env, timeout=600)
+    assert r.returncode == 0 and "RCCL_OK" in r.stdout, (r.returncode, r.stdout[-600:], r.stderr[-1500:])
+    line = [l for l in r.stdout.splitlines() if l.startswith("RCCL_OK")][0]
+    assert "librccl" in line
+    if not torch_first:
+        assert "torch" not in line, line                # no torch runtime in the process
