@@ -205,15 +205,6 @@ static int cp_launch_dev(hipStream_t st, int threads, int blocks, const CPArgs &
       hipError_t e = hipLaunchCooperativeKernel((const void *)ramx_cp_kernel<W, K, true>, dim3(blocks), dim3(threads), args, 0, st);
       return e == hipSuccess ? RAMX_OK : RAMX_ERR_HIP;
     }
-    // a.deep: the barrier-free variant of the vote-wave mode (RAMX_CP_DEEP=1), where the launch runs with a vote wave
-    if constexpr (CpCfg<W, K>::C <= RAMX_CP_SYNCW_MAXC)
-    {
-      if (a.deep && (CpCfg<W, K>::C <= RAMX_CP_SYNCW_REGC || a.vote_wave != 0))
-      {
-        hipLaunchKernelGGL((ramx_cp_kernel<W, K, true, true>), dim3(blocks), dim3(threads), 0, st, a);
-        return hipGetLastError() == hipSuccess ? RAMX_OK : RAMX_ERR_HIP;
-      }
-    }
     hipLaunchKernelGGL((ramx_cp_kernel<W, K, true>), dim3(blocks), dim3(threads), 0, st, a);
     return hipGetLastError() == hipSuccess ? RAMX_OK : RAMX_ERR_HIP;
   }

@@ -52,7 +52,6 @@ struct CPArgs
   int vote_wave;       // device-wide mode, blocks of up to RAMX_CP_SYNCW_MAXC cells: 1 = wave 0 of every workgroup runs the vote (ramx_cp_device_plan)
   int test_drop_row;   // test hook (RAMX_TEST_CP_DROP_TICKET=row): the last workgroup of every set withholds its words for that row; 0 = off
   int lean_p;            // P = max(0, largest matrix entry) of the LEAN test (ramx_kernels_cp.h band()); -1: never LEAN
-  int deep;              // 1: barrier-free variant of the vote-wave mode (band waves several rows ahead, LDS hand-off): RAMX_CP_DEEP=1
   int test_wrong_every;  // test hook (RAMX_TEST_CP_WRONG_EVERY=n): vote-wave mode, every n-th row is computed on a deliberately wrong guess; 0 = off
   int test_vote_delay;   // test hook (RAMX_TEST_CP_VOTE_DELAY=units): the vote wave idles that long before every row, so the band waves reach full depth
   int test_drop_id;    // ... of the set whose outputs index (CpDevDesc.id) is this one only; -1 = every set

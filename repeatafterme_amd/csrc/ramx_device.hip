@@ -890,16 +890,14 @@ static int prk_run(ramx_dev *d, const KArgs &a, int L, bool *used)
 }
 
 // test hooks of the vote-wave mode of the cell-parallel kernel (ramx_kernels_cp.h): RAMX_TEST_CP_WRONG_EVERY=n computes every
-// n-th row on a deliberately wrong guess, RAMX_TEST_CP_VOTE_DELAY=units holds the vote wave back so that the band waves are
-// DEPTH rows ahead when the decision arrives (rollbacks of full depth)
+// n-th row on a deliberately wrong guess, RAMX_TEST_CP_VOTE_DELAY=units holds the vote wave back so that the band waves have
+// finished their row on the guess when the decision arrives
 static void cp_test_hooks(CPArgs &ca)
 {
-  const char *we = getenv("RAMX_TEST_CP_WRONG_EVERY"), *vd = getenv("RAMX_TEST_CP_VOTE_DELAY"), *dp = getenv("RAMX_CP_DEEP");
+  const char *we = getenv("RAMX_TEST_CP_WRONG_EVERY"), *vd = getenv("RAMX_TEST_CP_VOTE_DELAY");
   ca.test_wrong_every = we ? atoi(we) : 0;
   ca.test_vote_delay = vd ? atoi(vd) : 0;
-  ca.deep = (dp && atoi(dp) != 0) ? 1 : 0;
-  // (the barrier-free variant rewinds rows: its band waves would have to rewind the LEAN test's previous-row best too)
-  ca.lean_p = ca.deep ? -1 : lean_p_of(ca.tab, ca.go, ca.ge);
+  ca.lean_p = lean_p_of(ca.tab, ca.go, ca.ge);
 }
 
 // ---- batch mode -------------------------------------------------------------------------------

@@ -37,15 +37,6 @@
 #define CP_F_GROUP 4          // fast path: cells per scheduling group (bounds the live ranges of the per-cell temporaries)
 #endif
 
-#ifndef CP_IDLE_SLEEP
-#define CP_IDLE_SLEEP 1       // barrier-free vote-wave mode: s_sleep units (64 clocks) of an idle wave's nap between two looks at the LDS words
-#endif
-// (s_wakeup -- waking the napping waves of the workgroup instead of letting them poll -- was tried and removed: with 576-thread
-// workgroups every launch ended in HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION on gfx950, and with 320-thread workgroups it was
-// not faster than short naps; profiles/r03_notes.md)
-#ifndef CP_SPEC_DEPTH
-#define CP_SPEC_DEPTH 2       // vote-wave mode, blocks of up to RAMX_CP_SYNCW_REGC cells: rows computed ahead of the confirmed vote (1..4)
-#endif
 
 #define CP_QP(a, b, c, d) "quad_perm:[" #a "," #b "," #c "," #d "]"
 
@@ -176,11 +167,6 @@ struct CpCfg
   // device-wide mode with a vote wave (RAMX_CP_SYNCW_MAXC): eight band waves and the vote wave while the saved row fits
   // the registers of nine waves (168 each); seven band waves and the vote wave when it is kept in LDS
   static constexpr int MAXT_DEV = C <= RAMX_CP_SYNCW_REGC ? 576 : MAXT;
-  // vote-wave mode: rows the band waves may run ahead of the confirmed vote (the last DEPTH rows of every band thread live in
-  // LDS: 16 * ceil(2C/4) bytes per thread and row), band threads and flanks of the largest workgroup
-  static constexpr int DEPTH = C <= 6 ? CP_SPEC_DEPTH : C <= RAMX_CP_SYNCW_REGC ? (CP_SPEC_DEPTH < 2 ? CP_SPEC_DEPTH : 2) : 1;
-  static constexpr int SPEC_THREADS = (MAXT_DEV > 64 ? MAXT_DEV - 64 : 64);
-  static constexpr int SPEC_FLANKS = SPEC_THREADS / K;
 };
 
 // per-lane constants of the cell-parallel band
@@ -421,17 +407,14 @@ __device__ __forceinline__ void cp_reduce(const CpLane &ln, const CpTabs &tabs, 
 #ifndef CP_MIN_WAVES_PER_SIMD
 #define CP_MIN_WAVES_PER_SIMD 2      // 512 threads, 2 waves per SIMD: 256 VGPRs
 #endif
-template <int W, int K, bool DEV, bool DEEP = false>
+template <int W, int K, bool DEV>
 __global__ __launch_bounds__((DEV ? (CpCfg<W, K>::MAXT_DEV > 0 ? CpCfg<W, K>::MAXT_DEV : 64) : (CpCfg<W, K>::MAXT > 0 ? CpCfg<W, K>::MAXT : 64)), CP_MIN_WAVES_PER_SIMD)
 void ramx_cp_kernel(const CPArgs a)
 {
   typedef CpCfg<W, K> Cfg;
   constexpr int B = Cfg::B, C = Cfg::C, NA = Cfg::NA, NWL = Cfg::NWL, FPW = 64 / K;
   constexpr bool SYNCW = DEV && C <= RAMX_CP_SYNCW_MAXC;  // device-wide mode, blocks of up to 21 cells: may run with a dedicated vote wave and speculative columns
-  // DEEPM: the barrier-free variant of the vote-wave mode -- band waves up to DEPTH rows ahead of the confirmed vote, meeting
-  // the vote wave through LDS words (RAMX_CP_DEEP=1; measured slower than the two-barrier variant)
-  constexpr bool DEEPM = DEEP && SYNCW;
-  const bool vw = SYNCW && (DEEPM || C <= RAMX_CP_SYNCW_REGC || a.vote_wave != 0);   // (blocks of 12..21 cells: the host chooses, ramx_cp_device_plan)
+  const bool vw = SYNCW && (C <= RAMX_CP_SYNCW_REGC || a.vote_wave != 0);   // (blocks of 12..21 cells: the host chooses, ramx_cp_device_plan)
   static_assert(K == 2 || K == 4 || K == 8 || K == 16, "lanes per flank");
   static_assert(B <= 255, "cell index must fit the key's low byte");
   struct Smem
@@ -440,14 +423,7 @@ void ramx_cp_kernel(const CPArgs a)
     unsigned long long vote[3][4];                   // DEV: [0..1] = this workgroup's partial sums (double buffered), [2] = the device-wide vote
     int fail, dec1, pad[2];                         // dec1: the vote wave's decision word for the band waves (SYNCW, two-barrier variant)
     // two-barrier variant, blocks of 12..21 cells: the row a band wave may have to restore (m then e, four values per 16-byte slot)
-    int4 save1[(SYNCW && !DEEPM && C > RAMX_CP_SYNCW_REGC) ? (2 * C + 3) / 4 : 1][(SYNCW && !DEEPM && C > RAMX_CP_SYNCW_REGC) ? 448 : 1];
-    // DEEPM: the meeting points of vote wave and band waves, see "speculative columns" below
-    unsigned long long S[2][8][4];                   // workgroup sums per (epoch parity, row & 7): low 40 bits sum, bits 40.. band waves that added
-    int dec[8];                                      // decisions of the vote wave, tagged with the row
-    unsigned long long rec[DEEPM ? 8 : 1][DEEPM ? Cfg::SPEC_FLANKS : 1];   // (high, pos << 32) of every flank after row (index & 7)
-    // the last DEPTH rows of every band thread (m then e, then the base window the row was computed from: w[0..NWL];
-    // four values per 16-byte slot)
-    int4 save[DEEPM ? Cfg::DEPTH : 1][DEEPM ? (2 * C + NWL + 1 + 3) / 4 : 1][DEEPM ? Cfg::SPEC_THREADS : 1];
+    int4 save1[(SYNCW && C > RAMX_CP_SYNCW_REGC) ? (2 * C + 3) / 4 : 1][(SYNCW && C > RAMX_CP_SYNCW_REGC) ? 448 : 1];
   };
   __shared__ __attribute__((aligned(16))) Smem sm;
   // wave index through readfirstlane: `live` must be PROVABLY wave-uniform, or the band sits in a divergent region and
@@ -487,8 +463,6 @@ void ramx_cp_kernel(const CPArgs a)
   }
   if (threadIdx.x < 12) sm.vote[threadIdx.x >> 2][threadIdx.x & 3] = 0ULL;
   if (threadIdx.x == 0) sm.fail = 0;
-  if (threadIdx.x < 64) sm.S[threadIdx.x >> 5][(threadIdx.x >> 2) & 7][threadIdx.x & 3] = 0ULL;
-  if (threadIdx.x < 8) sm.dec[threadIdx.x] = 0;
   __syncthreads();
 
   long long max_ext = 0;
@@ -561,248 +535,22 @@ void ramx_cp_kernel(const CPArgs a)
       for (int k = 0; k < 4; k++)
         v[k] += wave_sum_ll((other && !failed) ? (long long)(yy[k] & PEER_VMASK) - PEER_VBIAS : 0LL);
   };
-  // ---- speculative columns with a vote wave (SYNCW: device-wide mode, blocks of up to RAMX_CP_SYNCW_MAXC cells) --------
+  // ---- a vote wave (SYNCW: device-wide mode, blocks of up to RAMX_CP_SYNCW_MAXC cells) ------------------------------------
   // The vote of row r needs two trips through the memory fabric; the serial chain of the reference
-  // (ram_extend.c:1081-1085 feeding :970) is  decision(r) -> tickets(r+1) -> exchange -> decision(r+1).  Everything else
-  // leaves that chain:
-  //   * wave 0 holds no flank: it is the VOTE WAVE and runs nothing but the chain -- wait for the tickets of row r, fold,
-  //     decide, forward the workgroup's sums for row r+1 (already waiting in LDS) with the next ticket;
-  //   * the BAND WAVES run up to DEPTH rows ahead of the confirmed vote on the workgroup's own argmax of its candidate
-  //     sums (the guess), keeping the last DEPTH rows in LDS (sm.save) and the flank records of the last rows in sm.rec;
-  //   * no workgroup barrier inside the loop (gfx950 has ONE barrier per workgroup, and the vote wave must never stop at it
-  //     while it waits for a peer): the waves meet through LDS words --
-  //       sm.S[parity][row & 7][4]  the workgroup's sums for `row`: low 40 bits sum, bits 40.. = band waves that have added
-  //       sm.dec[row & 7]           the vote wave's decision on `row`, tagged with the row
-  //     both rings are 8 deep; DEPTH <= 4 keeps every reuse two confirmed rows away from its last reader (see the
-  //     zeroing rule in vote_loop).
-  // A wrong guess at row r (the decision says so: the vote wave compares the vote's winner with the argmax of the sums it
-  // forwarded for row r) starts a new EPOCH: the vote wave switches to the other parity of sm.S (cleared), the band waves
-  // restore the row before r from sm.save, recompute row r with the known winner and go on from there; what they had added
-  // for later rows under the wrong guess stays behind in the old parity.  Nothing computed from an unconfirmed guess ever
-  // leaves the workgroup -- the sums forwarded for row r+1 are always those of rows computed with confirmed winners -- so
-  // results cannot differ from the lock-step order.
-  // dec word: bits 0-1 winner, 2 new maximum, 3 stop, 4 failed, 5 epoch switch (the guess was wrong), 6 parity of sm.S from
-  // this row on, bits 12.. (row + 1) & 0xfffff
-  constexpr int DEPTH = Cfg::DEPTH;
-  constexpr unsigned long long CNT1 = 1ULL << 40, SUMMASK = CNT1 - 1;
-  const int nband = vw ? (int)(blockDim.x >> 6) - 1 : 0;
-  int nbw_live = (fd.nx + FPW - 1) / FPW;                 // band waves that hold flanks
-  nbw_live = nbw_live < nband ? nbw_live : nband;
+  // (ram_extend.c:1081-1085 feeding :970) is  decision(r) -> tickets(r+1) -> exchange -> decision(r+1).  Wave 0 holds no
+  // flank: it is the VOTE WAVE and runs nothing but the chain; the band waves compute row r on the workgroup's own argmax
+  // while the vote travels ("one speculative column" below).  (Round 3 also built a barrier-free variant that ran the band
+  // waves up to four rows ahead through LDS rings; it measured slower -- the device-wide chain, not the band, is the floor:
+  // profiles/r03_ab_spec5.log -- and was removed in round 4.)
   // test hook (RAMX_TEST_CP_WRONG_EVERY=n): the guess of every n-th row is replaced by another base, identically in the
-  // band waves and in the vote wave, so that rollbacks of every depth happen at known rows
+  // band waves and in the vote wave, so that rollbacks happen at known rows
   auto perturb = [&](const int row, const int g) __attribute__((always_inline)) -> int
   {
     if (a.test_wrong_every > 0 && ((row + 1) % a.test_wrong_every) == 0) return (g + 1 + (row / a.test_wrong_every) % 3) & 3;
     return g;
   };
-  // lanes 0..3 hold the four words of a sums slot: complete (every live band wave has added) -> argmax with the vote's tie rule
-  auto sums_ready = [&](const unsigned long long t, int &g) __attribute__((always_inline)) -> bool
-  {
-    unsigned long long cbest = 0;
-    bool ok = true;
-    g = 0;
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-    {
-      const unsigned long long vk = cp_readlane_u64(t, k);
-      ok = ok && (int)(vk >> 40) == nbw_live;
-      const unsigned long long sv = vk & SUMMASK;
-      if (sv > cbest) { cbest = sv; g = k; }
-    }
-    return ok;
-  };
-  auto lds_sums = [&](const int par, const int row) __attribute__((always_inline)) -> unsigned long long
-  {
-    return cp_lds_ld64(&sm.S[par][row & 7][lane & 3]);
-  };
 
-  // ---- the vote wave --------------------------------------------------------------------------------------------------
-  // tickets of row r have all arrived (bounded spin) -> this GPU's totals, plus the other ranks' through the mailboxes
-  auto wait_fold = [&](const int r, long long (&v)[4]) __attribute__((always_inline))
-  {
-    const unsigned long long *src = vote_src(r);
-    unsigned spins = 0;
-    // workgroup 0: the clearing stores of the previous decision (set of row r+2) are complete before this wave sends its
-    // next ticket (see publish)
-    if (wg == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    unsigned long long x0 = 0, x1 = 0;
-#ifdef CP_PROBE_NO_WAIT          // timing probe only (wrong results): whatever has arrived is the vote
-    bool done = true;
-#else
-    bool done = my_shard_blocks <= 0;
-#endif
-    __builtin_amdgcn_s_sleep(CP_SYNC_FIRST_SLEEP);   // the tickets were sent a moment ago: they need half a microsecond to land
-    for (;;)
-    {
-      if (!done)
-      {
-        typedef unsigned v4u __attribute__((ext_vector_type(4)));
-        v4u q;
-        asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(q) : "v"(src) : "memory");
-        x0 = ((unsigned long long)q.y << 32) | q.x;
-        x1 = ((unsigned long long)q.w << 32) | q.z;
-        done = (x0 >> 54) >= (unsigned long long)my_shard_blocks && (x1 >> 54) >= (unsigned long long)my_shard_blocks;
-      }
-      if (__all(done)) break;
-      if (++spins > PRK_SPIN_LIMIT || ((spins & 1023u) == 0 && __hip_atomic_load(errw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0))
-      {
-        failed = 1;
-        break;
-      }
-    }
-    if (my_shard_blocks <= 0 || failed) { x0 = 0; x1 = 0; }
-    x0 = cp_row_sum_u64(x0); x1 = cp_row_sum_u64(x1);
-    {
-      const unsigned long long t0 = cp_readlane_u64(x0, 0) + cp_readlane_u64(x0, 16), t1 = cp_readlane_u64(x1, 0) + cp_readlane_u64(x1, 16);
-      const unsigned long long t2 = cp_readlane_u64(x0, 32) + cp_readlane_u64(x0, 48), t3 = cp_readlane_u64(x1, 32) + cp_readlane_u64(x1, 48);
-      v[0] = (long long)(t0 & (PRK_TICKET - 1)) - (long long)(t0 >> 54) * (long long)PRK_BIAS;
-      v[1] = (long long)(t1 & (PRK_TICKET - 1)) - (long long)(t1 >> 54) * (long long)PRK_BIAS;
-      v[2] = (long long)(t2 & (PRK_TICKET - 1)) - (long long)(t2 >> 54) * (long long)PRK_BIAS;
-      v[3] = (long long)(t3 & (PRK_TICKET - 1)) - (long long)(t3 >> 54) * (long long)PRK_BIAS;
-    }
-    if (a.nranks > 1 && !failed) cross_device(r, v);
-  };
   int respec = 0;                                    // vote wave: epoch switches (mispredicted rows)
-  auto vote_loop = [&]() __attribute__((always_inline))
-  {
-    int par = 0, g = 0;
-    // the chain runs in this wave alone: it goes first wherever it shares a SIMD with a band wave
-    __builtin_amdgcn_s_setprio(3);
-    // the sums for `row` under the current epoch are complete (bounded spin on LDS; normally they have been waiting):
-    // forward them with the ticket for `row`
-    auto forward = [&](const int row, const bool spin) __attribute__((always_inline)) -> bool
-    {
-      unsigned spins = 0;
-      for (;;)
-      {
-        const unsigned long long t = lds_sums(par, row);
-        int g1;
-        if (sums_ready(t, g1))
-        {
-          if (lane < 4) send_words(row - 1, t & SUMMASK);
-          g = perturb(row, g1);
-          return true;
-        }
-        if (!spin) return false;
-        if (++spins > PRK_SPIN_LIMIT) { failed = 1; return false; }
-        __builtin_amdgcn_s_sleep(CP_IDLE_SLEEP);      // (the band wave that completes the sums wakes this one)
-      }
-    };
-    forward(0, true);
-#ifdef RAMX_CP_TIMING
-    sp_last = __builtin_amdgcn_s_memtime();
-#endif
-    for (int r = 0; r < a.L && !failed; r++)
-    {
-      SP_TICK(3);                // loop bookkeeping
-      if (a.test_vote_delay > 0) for (int q = 0; q < a.test_vote_delay; q++) __builtin_amdgcn_s_sleep(127);   // test hook: the band waves reach full depth
-      long long v[4];
-      wait_fold(r, v);
-      SP_TICK(0);                // tickets of row r: wait, fold (cross-device step)
-      if (failed) break;
-      // ---- winner (ram_extend.c:1081-1085) ----
-      int besta = 0;
-      unsigned chi = 0, clo = 0;
-#pragma unroll
-      for (int k = 0; k < 4; k++)
-      {
-        const unsigned hi = (unsigned)((unsigned long long)v[k] >> 32), lo = (unsigned)(unsigned long long)v[k];
-        if (hi != 0 || lo > 2147483647u) ovf = 1;                  // the reference's int accumulator would have wrapped
-        if (hi > chi || (hi == chi && lo > clo)) { chi = hi; clo = lo; besta = k; }
-      }
-#if defined(CP_PROBE_NO_WAIT) || defined(CP_PROBE_NO_BAND)
-      const bool wrong = false;  // timing probes only (wrong results)
-#else
-      const bool wrong = besta != g;
-#endif
-      // the chain's next link first: when the guess was right the sums for row r+1 are valid as they stand -- forward them
-      // at once (a ticket for the row after a stop row is never looked at)
-      bool sent = false;
-      if (!wrong && r + 1 < a.L) sent = forward(r + 1, false);
-      SP_TICK(1);                // winner, forward at once
-#ifdef RAMX_CP_TIMING
-      if (sent) sp_t[5] += 1;    // rows forwarded without waiting for the band waves
-#endif
-      // ---- stop rule (ram_extend.c:1194-1216) ----
-      const long long curr = (long long)(((unsigned long long)chi << 32) | clo);
-      int dist = max_row - r;
-      dist = dist < 0 ? -dist : dist;
-      const bool new_max = curr >= max_ext + (long long)dist * a.minimp;
-      if (new_max) { max_row = r; max_ext = curr; }
-      int d2 = r - max_row;
-      d2 = d2 < 0 ? -d2 : d2;
-      stopped = d2 >= a.when_to_stop;
-      rows_done = r + 1;
-      // ---- the sums ring: a wrong guess starts a new epoch on the other (cleared) parity; otherwise the slot of row r-1 is
-      // cleared for row r+7.  Every band wave has computed row r-1 by now (this workgroup's ticket for row r needed their
-      // sums) and none is further than DEPTH <= 4 rows past the last decision it has seen, so nobody reads or adds to that
-      // slot; the new parity was last written two epochs ago, and every band wave has entered the epoch in between.
-      if (wrong)
-      {
-        par ^= 1;
-        respec++;
-        if (lane < 32) cp_lds_st64(&sm.S[par][lane >> 2][lane & 3], 0ULL);
-      }
-      else if (lane < 4) cp_lds_st64(&sm.S[par][(r - 1) & 7][lane], 0ULL);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (lane == 0)
-        cp_lds_st32(&sm.dec[r & 7], besta | (new_max ? 4 : 0) | (stopped ? 8 : 0) | (wrong ? 32 : 0) | (par << 6) | (((r + 1) & 0xfffff) << 12));
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (wg == 0)
-      {
-        if (lane == 0) a.cons_out[(size_t)dd.id * a.L + r] = (signed char)besta;
-        if (lane < NSHARD)            // workgroup 0 clears the device set of row r+3 (see publish)
-        {
-          PShard *z = vote + (size_t)((r + 3) & (RAMX_CP_NSETS - 1)) * NSHARD + lane;
-#pragma unroll
-          for (int k = 0; k < 4; k++) __hip_atomic_store(&z->word[k], 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-      }
-      SP_TICK(2);                // stop rule, decision word, consensus byte, clearing
-      if (stopped || r == a.L - 1) break;
-      if (!sent) forward(r + 1, true);               // after a wrong guess: the band waves recompute row r first
-      SP_TICK(4);                // waiting for the band waves' sums
-    }
-    if (failed)
-    {
-      // the band waves take decisions in order and never pass a row without one: the "failed" word of the first undecided
-      // row reaches all of them
-      if (lane == 0)
-      {
-        cp_lds_st32(&sm.dec[rows_done & 7], 16 | (((rows_done + 1) & 0xfffff) << 12));
-        __hip_atomic_store(errw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
-  };
-
-  // The vote wave leaves here: nothing of the band state below is ever live in it (register allocation is per function: values
-  // defined before this point and used inside its loop would be spilled where the band prologue is at its peak and reloaded
-  // from scratch on the critical chain)
-  if constexpr (DEEPM)
-  {
-    if (vw && wave == 0)
-    {
-      if (a.L > 0) vote_loop();
-#ifdef RAMX_CP_TIMING
-      if (a.dbg != NULL && blockIdx.x == 0 && lane == 0)
-      {
-#pragma unroll
-        for (int k = 0; k < 8; k++) a.dbg[k] = sp_t[k];
-        a.dbg[16 * 16] = (unsigned long long)rows_done;
-      }
-#endif
-      if (threadIdx.x == 0 && wg == 0)
-      {
-        RamxCtl o;
-        o.max_ext = max_ext; o.max_row = max_row; o.stopped = stopped; o.rows_done = rows_done; o.overflow = ovf;
-        o.besta = respec;    // rows recomputed after a wrong guess
-        o.pad = failed;
-        a.ctl_out[fd.id] = o;
-      }
-      return;
-    }
-  }
 
 
   CpLane ln;
@@ -1038,22 +786,7 @@ void ramx_cp_kernel(const CPArgs a)
       finish_column(bestA, contrib);
       window_words(AE, AO);
     }
-    if constexpr (DEEPM)
-    {
-      if (vw)
-      {
-        // barrier-free vote-wave mode: row 0's sums go into the sums ring (parity 0, slot 0), the records "after row -1" into the records
-        // ring; the vote wave picks the sums up from there -- no barrier
-        if (live)
-        {
-          cp_flank_sum4<K>(contrib);
-          add4_lds(sm.S[0][0], contrib[0] + (1ULL << 40), contrib[1] + (1ULL << 40), contrib[2] + (1ULL << 40), contrib[3] + (1ULL << 40));
-          if (ln.pL0 && active) sm.rec[7][f] = 0ULL;
-        }
-      }
-      else publish(-1, contrib);
-    }
-    else publish(-1, contrib);
+    publish(-1, contrib);
   }
 
   // One column.  The fast and the masked variant are two separate loops below (a wave switches between them when its
@@ -1090,163 +823,7 @@ void ramx_cp_kernel(const CPArgs a)
     else cp_reduce<W, K, G>(ln, sm.tabs, AE, AO, m, e, bestF, jb, bestA);
     CP_TICK(3);                  // reductions
   };
-  // ---- the band waves ---------------------------------------------------------------------------------------------------
-  constexpr int NSV = 2 * C + NWL + 1;               // values of a saved row: m, e, then the base window w[0..NWL] (not wpre: its load may still be in flight)
-  constexpr int G4 = (NSV + 3) / 4;                  // 16-byte slots
-  const int bt = vw ? (int)threadIdx.x - 64 : 0;     // band thread index
-  auto row_value = [&](auto qc) __attribute__((always_inline)) -> int &
-  {
-    constexpr int q = decltype(qc)::value;           // 0 .. C-1: m, C .. 2C-1: e, then w[0..NWL], wpre
-    if constexpr (q < C) return m[q];
-    else if constexpr (q < 2 * C) return e[q - C];
-    else return reinterpret_cast<int &>(w[q - 2 * C]);
-  };
-  auto save_row = [&](const int slot) __attribute__((always_inline))
-  {
-    if constexpr (DEEPM)
-    static_for([&](auto gq) __attribute__((always_inline))
-    {
-      constexpr int g = decltype(gq)::value;
-      int4 v = make_int4(0, 0, 0, 0);
-      v.x = row_value(std::integral_constant<int, 4 * g>{});
-      if constexpr (4 * g + 1 < NSV) v.y = row_value(std::integral_constant<int, (4 * g + 1 < NSV ? 4 * g + 1 : 0)>{});
-      if constexpr (4 * g + 2 < NSV) v.z = row_value(std::integral_constant<int, (4 * g + 2 < NSV ? 4 * g + 2 : 0)>{});
-      if constexpr (4 * g + 3 < NSV) v.w = row_value(std::integral_constant<int, (4 * g + 3 < NSV ? 4 * g + 3 : 0)>{});
-      sm.save[slot][g][bt] = v;
-    }, std::make_integer_sequence<int, G4>{});
-  };
-  auto load_row = [&](const int slot) __attribute__((always_inline))
-  {
-    if constexpr (DEEPM)
-    static_for([&](auto gq) __attribute__((always_inline))
-    {
-      constexpr int g = decltype(gq)::value;
-      const int4 v = sm.save[slot][g][bt];
-      row_value(std::integral_constant<int, 4 * g>{}) = v.x;
-      if constexpr (4 * g + 1 < NSV) row_value(std::integral_constant<int, (4 * g + 1 < NSV ? 4 * g + 1 : 0)>{}) = v.y;
-      if constexpr (4 * g + 2 < NSV) row_value(std::integral_constant<int, (4 * g + 2 < NSV ? 4 * g + 2 : 0)>{}) = v.z;
-      if constexpr (4 * g + 3 < NSV) row_value(std::integral_constant<int, (4 * g + 3 < NSV ? 4 * g + 3 : 0)>{}) = v.w;
-    }, std::make_integer_sequence<int, G4>{});
-  };
-  int spec = 0, conf = 0, bpar = 0, fixed_row = -2;   // next row to compute, rows confirmed, parity of sm.S, row recomputed after an epoch switch
-  bool finished = false;
-  // back to the state "row x computed, ready for row x+1" (conf-1 <= x < spec-1): the row and its base window from the save ring
-  // (saved when row x+1 was computed), the records from the records ring -- LDS only
-  auto rewind_to = [&](const int x) __attribute__((always_inline))
-  {
-    load_row((x + 1) % DEPTH);
-    const unsigned long long hp = cp_lds_ld64(&sm.rec[x & 7][live ? f : 0]);
-    high = (int)(unsigned)hp; pos = (int)(unsigned)(hp >> 32);
-    s = ln.j0 + x + 9;                               // the window for row x+1 (its words came back with the row)
-    {
-      const int wn = (s >> 3) + 1 + NWL;             // the word the next slide brings in: fetched again
-      wpre = a.bases[(size_t)(wn < a.KW ? wn : a.KW - 1) * a.Np + n];
-    }
-    window_words(AE, AO);
-    spec = x + 1;
-  };
-  int next_row = -1, next_win = 0, snap_row = -1, fresh_d = 0;
-  unsigned long long fresh_t = 0;
-  bool fresh = false;
-  auto take_snapshot = [&]() __attribute__((always_inline))
-  {
-    if (snap_row >= 0)
-    {
-      const unsigned long long hp = cp_lds_ld64(&sm.rec[snap_row & 7][live ? f : 0]);
-      thigh = (int)(unsigned)hp; tpos = (int)(unsigned)(hp >> 32);
-      snap_row = -1;
-    }
-  };
-  // what to do next: take in the decisions that have arrived (records snapshot, stop, epoch switch), then either a row to
-  // compute (next_row >= 0, against next_win) or nothing yet (next_row < 0: the caller sleeps and asks again)
-  auto plan = [&]() __attribute__((always_inline))
-  {
-    next_row = -1;
-    for (;;)
-    {
-      // the decision word of the first undecided row and the sums of the next row to speculate on: one LDS round trip
-      int d;
-      unsigned long long t;
-      if (fresh)
-      {
-        // straight after a row: the row's own addition to the sums came back with what the slot held, and the decision word was
-        // read in the same breath (compute_row)
-        d = fresh_d; t = fresh_t; fresh = false;
-      }
-      else
-      {
-        asm volatile("ds_read_b32 %0, %2\n\tds_read_b64 %1, %3\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&v"(d), "=&v"(t) : "v"(cp_lds_off(&sm.dec[conf & 7])), "v"(cp_lds_off(&sm.S[bpar][spec & 7][lane & 3])) : "memory");
-        d = __builtin_amdgcn_readfirstlane(d);
-      }
-      if (((unsigned)d >> 12) != (unsigned)((conf + 1) & 0xfffff))
-      {
-        // no decision on row `conf` yet: speculate on the workgroup's own sums, at most DEPTH rows past the last decision
-        if (spec - conf >= DEPTH || spec >= a.L) return;
-        int g1;
-        if (!sums_ready(t, g1)) return;
-        next_row = spec; next_win = perturb(spec, g1);
-        return;
-      }
-      if (d & 16) { failed = 1; finished = true; return; }
-      if ((d & 32) && fixed_row != conf)
-      {
-        // the guess for row `conf` was wrong: new epoch.  Back to the row before it, then row `conf` with the known winner
-        bpar = (d >> 6) & 1;
-        fixed_row = conf;
-        if (spec > conf) rewind_to(conf - 1);
-        next_row = conf; next_win = d & 3;
-        return;
-      }
-      if (spec == conf) { next_row = conf; next_win = d & 3; return; }   // the decision got here first: no guess needed
-      // new maximum at row `conf`: the flank records after that row become the trimmed ones (:1203-1207).  Only the last
-      // such row counts, so the copy is put off until the records ring is about to overwrite it (or the loop ends)
-      if (d & 4) snap_row = conf;
-      conf++;
-      if ((d & 8) || conf == a.L)
-      {
-        take_snapshot();
-        if (spec > conf) rewind_to(conf - 1);        // rows computed past the last executed one are dropped
-        finished = true;
-        return;
-      }
-      if (snap_row >= 0 && conf - snap_row >= 3) take_snapshot();   // (rows up to conf + DEPTH - 1 <= snap_row + 6 have been written)
-    }
-  };
-  auto compute_row = [&](auto gc) __attribute__((always_inline))
-  {
-    constexpr bool G = decltype(gc)::value;
-    const int row = next_row;
-    int bestA[4] = { 0, 0, 0, 0 }, bestF = 0, jb = 0;
-    unsigned contrib[4] = { 0, 0, 0, 0 };
-    if (G) set_masks(row);
-    save_row(row % DEPTH);
-    band(row, next_win, gc, bestF, jb, bestA);
-    if (bestF > high) { high = bestF; pos = row + jb - W; }      // ram_extend.c:1140-1150
-    if (ln.pL0 && active) cp_lds_st64(&sm.rec[row & 7][f], (unsigned long long)(unsigned)high | ((unsigned long long)(unsigned)pos << 32));
-    contributions(bestA, high, contrib);
-    cp_flank_sum4<K>(contrib);
-    slide_window();
-    window_words(AE, AO);        // next row's window
-    spec = row + 1;
-    // This wave's part of the sums for row + 1: lanes 0..3 add one word each with a RETURNING atomic, so the wave learns in the
-    // same LDS round trip whether it was the last band wave to add (then the sums are complete and it has them: the guess for
-    // the next row needs no second look), and the decision word of the first undecided row comes back with it.
-    {
-      const unsigned long long mine = (lane == 0 ? contrib[0] : lane == 1 ? contrib[1] : lane == 2 ? contrib[2] : contrib[3]) + CNT1;
-      unsigned long long pre = 0;
-      int d = 0;
-      if (lane < 4)
-        asm volatile("ds_add_rtn_u64 %0, %2, %3\n\tds_read_b32 %1, %4\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&v"(pre), "=&v"(d)
-                     : "v"(cp_lds_off(&sm.S[bpar][spec & 7][lane & 3])), "v"(mine), "v"(cp_lds_off(&sm.dec[conf & 7])) : "memory");
-      fresh_t = pre + mine;
-      fresh_d = __builtin_amdgcn_readfirstlane(d);
-      fresh = true;
-    }
-  };
-
-  // ---- one speculative column with a vote wave and two workgroup barriers (SYNCW, not DEEP: the default) -------------------
+  // ---- one speculative column with a vote wave and two workgroup barriers (SYNCW) --------------------------------------------
   // The vote of row r needs two trips through the memory fabric.  Meanwhile the band waves compute row r against the
   // WORKGROUP'S OWN argmax of the candidate sums (guess) and carry the speculation through the flank records, the
   // contributions to row r+1 and their workgroup sums (barrier A).  Wave 0 holds no flank: during the band it waits for the
@@ -1490,11 +1067,11 @@ void ramx_cp_kernel(const CPArgs a)
     if (wave == 0) return sync_column(r);
     return band_column(r, gc);
   };
-  if (vw && !DEEPM && a.L > 0) guess_cur = perturb(0, argmax4_lds(sm.vote[0]));     // row 0's workgroup sums (complete since the barrier of column -1)
+  if (vw && a.L > 0) guess_cur = perturb(0, argmax4_lds(sm.vote[0]));     // row 0's workgroup sums (complete since the barrier of column -1)
   auto column = [&](const int r, auto gc) __attribute__((always_inline)) -> bool
   {
     constexpr bool G = decltype(gc)::value;
-    if constexpr (SYNCW && !DEEPM) { if (vw) return column_spec(r, gc); }
+    if constexpr (SYNCW) { if (vw) return column_spec(r, gc); }
     CP_TICK(7);                  // barrier released .. loop top
     int bestA[4] = { 0, 0, 0, 0 }, bestF = 0, jb = 0;
     if (G && live) set_masks(r);
@@ -1571,59 +1148,6 @@ void ramx_cp_kernel(const CPArgs a)
 #ifdef RAMX_CP_TIMING
   tlast = __builtin_amdgcn_s_memtime();
 #endif
-  bool spec_mode = false;
-  if constexpr (DEEPM) spec_mode = vw;
-  if (spec_mode)
-  {
-    if constexpr (DEEPM)
-    {
-      if (a.L > 0)
-      {
-        if (live)
-        {
-          // the fast and the masked variant of the band are two separate loops, as below
-          unsigned idle = 0;
-#ifdef RAMX_CP_TIMING
-          sp_last = __builtin_amdgcn_s_memtime();
-#endif
-          plan();
-          while (!finished)
-          {
-            if (next_row < 0)
-            {
-              if (++idle > (PRK_SPIN_LIMIT << 3)) { failed = 1; break; }      // (the vote wave's own limits fire long before)
-              // a short nap between two looks at the LDS words
-              __builtin_amdgcn_s_sleep(CP_IDLE_SLEEP);
-              plan();
-              SP_TICK(0);        // idle: no decision, no sums (or DEPTH rows ahead)
-              continue;
-            }
-            idle = 0;
-            if (is_fast(next_row))
-            {
-              do { SP_TICK(1); compute_row(std::false_type{}); SP_TICK(2); plan(); } while (!finished && next_row >= 0 && is_fast(next_row));
-            }
-            else
-            {
-              SP_TICK(1);
-              compute_row(std::true_type{});
-              SP_TICK(2);        // a row
-              plan();
-            }
-            SP_TICK(1);          // planning
-          }
-#ifdef RAMX_CP_TIMING
-          if (a.dbg != NULL && blockIdx.x == 0 && lane == 0)
-          {
-#pragma unroll
-            for (int k = 0; k < 8; k++) a.dbg[wave * 16 + k] = sp_t[k];
-          }
-#endif
-        }
-      }
-    }
-  }
-  else
   for (int r = 0; r < a.L;)
   {
     bool end = false;
