@@ -70,3 +70,23 @@ def test_reference_fixture_family():
     assert len(seed.rf) == width and all(len(r.aligned) == width for r in seed.rows)
     assert len(stk.reference_sequence(seed)) == seed.rf.lower().count("x") == 66
     assert 5.0 < stk.kimura_divergence(seed) < 30.0
+
+
+def test_flag_rule_and_scoring_ladder_against_the_wrapper_vectors():
+    """tests/golden/stk_vectors.json: made by tests/golden/make_stk_vectors.pl -- Perl, with the reference wrapper's own regular
+    expressions (util/extend-stk.pl:330-346), its start - 1 (:314), its gi|NNN rule (:308-311), its 'more than 3 extendable rows'
+    (:364) and its divergence -> matrix / -minimprovement ladder (:291-302) -- on the reference's three fixtures
+    test/ce10-fam{1,2,3}.stk (copies under tests/golden/inputs/)."""
+    import json
+    doc = json.load(open(os.path.join(HERE, "golden", "stk_vectors.json")))
+    assert [f["file"] for f in doc["families"]] == ["ce10-fam1.stk", "ce10-fam2.stk", "ce10-fam3.stk"]
+    for fam in doc["families"]:
+        seed, = stk.read_stockholm(os.path.join(HERE, "golden", "inputs", fam["file"]))
+        rows, extendable = stk.ranges_for(seed)
+        assert [list(r) for r in rows] == fam["rows"], fam["file"]
+        assert extendable == fam["extendable_count"] and (extendable > 3) == fam["runs_ramextend"]
+        # no mDiv in these descriptions: the divergence is the computed one (:279-283)
+        assert fam["mDiv"] is None and stk.family_divergence(seed) == stk.kimura_divergence(seed)
+    assert any(r[3:5] != [1, 1] for r in doc["families"][2]["rows"])      # fam3 has rows that miss an edge: the rule is exercised
+    for tdiv, mas, matrix, minimp in doc["scoring_ladder"]:
+        assert stk.choose_scoring(tdiv, mas) == (matrix, minimp), (tdiv, mas)
