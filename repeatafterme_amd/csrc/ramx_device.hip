@@ -127,6 +127,8 @@ struct ramx_dev
   int *d_dbg_cand; int2 *d_dbg_gap; size_t cap_dbg_cand, cap_dbg_gap;
   CpDevDesc *d_devdesc; size_t cap_devdesc;       // device-wide cell-parallel launches: one descriptor per workgroup
   PShard *d_vote_sets; size_t cap_vote_sets; unsigned *d_err_sets; size_t cap_err_sets;   // batch mode: per-set vote / error words
+  int packed_kw;       // words of every window packed so far (begin_direction packs the first piece, see pack_rest)
+  hipStream_t pack_stream; hipEvent_t pack_done; int pack_busy;      // the following pieces are packed beside the running one
   int pk_r0;           // begin_direction: first row from which no flank has a low out-of-bounds cell (the packed-row kernel starts there); -1: none
   int last_packed_r0;  // last direction: first row of the packed-row kernel, -1 if it did not run
   int cp_flanks_ok;    // begin_direction: every flank is empty or has t_lo <= 0 (what the cell-parallel kernels take)
@@ -160,6 +162,8 @@ extern "C" int ramx_dev_create(int ordinal, ramx_dev **out)
 #define CRCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
     ramx_set_error("HIP error %s at %s:%d (%s)", hipGetErrorString(e_), __FILE__, __LINE__, #call); ramx_dev_destroy(d); return RAMX_ERR_HIP; } } while (0)
   CRCHK(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
+  CRCHK(hipStreamCreateWithFlags(&d->pack_stream, hipStreamNonBlocking));
+  CRCHK(hipEventCreateWithFlags(&d->pack_done, hipEventDisableTiming));
   CRCHK(hipHostMalloc((void **)&d->h_ctl, 4 * sizeof(RamxCtl), hipHostMallocDefault));
   CRCHK(hipMalloc((void **)&d->d_sums, (3 * NSHARD * 4 + 8) * sizeof(long long)));
   CRCHK(hipMalloc((void **)&d->d_ctl, 2 * sizeof(RamxCtl)));
@@ -182,6 +186,8 @@ extern "C" void ramx_dev_destroy(ramx_dev *d)
   if (!d) return;
   (void)hipSetDevice(d->ordinal);
   if (d->stream) (void)hipStreamSynchronize(d->stream);
+  if (d->pack_stream) { (void)hipStreamSynchronize(d->pack_stream); (void)hipStreamDestroy(d->pack_stream); }
+  if (d->pack_done) (void)hipEventDestroy(d->pack_done);
   if (d->comm) (void)ncclCommDestroy(d->comm);
   // mappings of the other ranks' mailboxes (hipIpcOpenMemHandle): closed before anything of this device is released
   for (int q = 0; q < RAMX_MAX_RANKS; q++)
@@ -267,31 +273,54 @@ extern "C" int ramx_dev_load_library_packed(ramx_dev *d, const struct ramx_packe
   return RAMX_OK;
 }
 
-// flank descriptors (already on the device) -> transposed, pre-oriented 4-bit windows + bounds, from either kind of library
-static int launch_pack(ramx_dev *d, int Nx, int Np, int KW, int W)
+// flank descriptors (already on the device) -> transposed, pre-oriented 4-bit windows + bounds, from either kind of library:
+// words [k_lo, k_hi) of every flank's window, on stream `st`
+static int launch_pack(ramx_dev *d, int Nx, int Np, int W, int k_lo, int k_hi, hipStream_t st)
 {
-  dim3 grid((Np + 255) / 256, KW);
+  if (k_hi <= k_lo) return RAMX_OK;
   if (!d->lib_packed)
   {
-    hipLaunchKernelGGL(ramx_pack_kernel, grid, dim3(256), 0, d->stream, d->d_lib, (unsigned long long)d->lib_len,
-                       d->d_flanks, Nx, Np, W, d->d_bases, d->d_bounds);
+    dim3 grid((Np + 255) / 256, k_hi - k_lo);
+    hipLaunchKernelGGL(ramx_pack_kernel, grid, dim3(256), 0, st, d->d_lib, (unsigned long long)d->lib_len,
+                       d->d_flanks, Nx, Np, W, k_lo, d->d_bases, d->d_bounds);
     HIPCHK(hipGetLastError());
     return RAMX_OK;
   }
-  int rc;
-  if ((rc = ensure(&d->d_flank_win, &d->cap_flank_win, (size_t)Np * sizeof(int)))) return rc;
   PkLib L;
   L.bytes = d->d_pk_bytes; L.win_start = d->d_pk_wstart; L.win_byte = d->d_pk_wbyte; L.win_phase = d->d_pk_phase;
   L.n_start = d->d_pk_nstart; L.n_len = d->d_pk_nlen; L.length = d->lib_len; L.n_windows = d->pk_windows; L.n_blocks = d->pk_nblocks;
-  if (Nx > 0)
+  if (k_lo == 0)
   {
-    hipLaunchKernelGGL(ramx_flank_window_kernel, dim3((Nx + 255) / 256), dim3(256), 0, d->stream, L, d->d_flanks, Nx, d->d_flank_win);
-    HIPCHK(hipGetLastError());
+    int rc;
+    if ((rc = ensure(&d->d_flank_win, &d->cap_flank_win, (size_t)Np * sizeof(int)))) return rc;
+    if (Nx > 0)
+    {
+      hipLaunchKernelGGL(ramx_flank_window_kernel, dim3((Nx + 255) / 256), dim3(256), 0, st, L, d->d_flanks, Nx, d->d_flank_win);
+      HIPCHK(hipGetLastError());
+    }
   }
-  hipLaunchKernelGGL(ramx_pack2_kernel, dim3((Np + 255) / 256, (KW + RAMX_PK_WORDS - 1) / RAMX_PK_WORDS), dim3(256), 0, d->stream, L, d->d_flanks,
-                     d->d_flank_win, Nx, Np, W, KW, d->d_bases, d->d_bounds);
+  hipLaunchKernelGGL(ramx_pack2_kernel, dim3((Np + 255) / 256, (k_hi - k_lo + RAMX_PK_WORDS - 1) / RAMX_PK_WORDS), dim3(256), 0, st, L, d->d_flanks,
+                     d->d_flank_win, Nx, Np, W, k_lo, k_hi, d->d_bases, d->d_bounds);
   HIPCHK(hipGetLastError());
   return RAMX_OK;
+}
+
+// A direction's windows are L + 2W columns long, and most runs stop after a fraction of them (the reference's default: 100 columns
+// behind the end of the alignment): begin_direction packs the first RAMX_PK_SEGMENT columns, the packed-row route packs the
+// following pieces on a second stream while the piece before them runs (prk_run), and every other route packs the rest here.
+static int pack_rest(ramx_dev *d)
+{
+  if (d->packed_kw >= d->KW) return RAMX_OK;
+  if (d->pack_busy) { HIPCHK(hipStreamWaitEvent(d->stream, d->pack_done, 0)); d->pack_busy = 0; }
+  const int rc = launch_pack(d, d->Nx, d->Np, d->p.bandwidth, d->packed_kw, d->KW, d->stream);
+  d->packed_kw = d->KW;
+  return rc;
+}
+static int pk_segment_columns(void)
+{
+  const char *e = getenv("RAMX_PK_SEGMENT");
+  const int v = e ? atoi(e) : 2048;
+  return v < 0 ? 0 : v;          // 0: the whole direction in one piece (everything packed at once)
 }
 
 template <typename T>
@@ -345,7 +374,13 @@ extern "C" int ramx_dev_begin_direction(ramx_dev *d, const ramx_flank *flanks, i
   }
   if ((rc = ensure(&d->d_cons, &d->cap_cons, (size_t)p->L + 16))) return rc;
   if (Nx) HIPCHK(hipMemcpyAsync(d->d_flanks, flanks, (size_t)Nx * sizeof(ramx_flank), hipMemcpyHostToDevice, d->stream));
-  if ((rc = launch_pack(d, Nx, Np, KW, W)) != RAMX_OK) return rc;
+  {
+    if (d->pack_busy) { HIPCHK(hipStreamWaitEvent(d->stream, d->pack_done, 0)); d->pack_busy = 0; }    // (a piece of the direction before still in flight)
+    const int seg = pk_segment_columns();
+    const int first = seg > 0 ? ((seg + 8) >> 3) + 28 : KW;      // words the first piece's columns read (+ the widest band's window and look-ahead)
+    d->packed_kw = first < KW ? first : KW;
+    if ((rc = launch_pack(d, Nx, Np, W, 0, d->packed_kw, d->stream)) != RAMX_OK) return rc;
+  }
   HIPCHK(hipMemsetAsync(d->d_sums, 0, 3 * NSHARD * 4 * sizeof(long long), d->stream));
   HIPCHK(hipMemsetAsync(d->d_cons, 0, (size_t)p->L + 16, d->stream));
   HIPCHK(hipStreamSynchronize(d->stream));
@@ -688,6 +723,23 @@ static int prk_local_can(ramx_dev *d, const KArgs &a, int L, bool multi, bool *c
   return RAMX_OK;
 }
 
+// Will the packed-row kernel (ramx_kernels_packed.h) take this direction (from row d->pk_r0 on)?  Single GPU, a scoring system whose
+// rows fit int16 relative to a per-flank base, the flank set resident, and -- where flanks have low out-of-bounds cells in the
+// first rows -- the int32 kernel for those rows.
+static int pk_route(ramx_dev *d, const KArgs &a, int L, bool multi, bool int32_can, bool *pk_out, int *spread, int *rebase, int *pk_block, int *pk_blocks)
+{
+  *pk_out = false; *pk_block = 0; *pk_blocks = 0;
+  const int pk_r0 = (getenv("RAMX_NO_PERSISTENT") != NULL || d->force_chain || L <= 0) ? -1 : d->pk_r0;
+  bool pk = !multi && pk_r0 >= 0 && pk_r0 < L && ramx_pk_plan(a.W, a.go, a.ge, a.tab, spread, rebase) != 0;
+  if (pk)
+  {
+    if (ramx_pk_shape(a.W, d->Np / 64, pk_block, pk_blocks) != RAMX_OK) { ramx_set_error("packed-row kernel: occupancy query failed"); return RAMX_ERR_HIP; }
+    if (*pk_block == 0 || (pk_r0 > 0 && !int32_can)) pk = false;
+  }
+  *pk_out = pk;
+  return RAMX_OK;
+}
+
 static int prk_run(ramx_dev *d, const KArgs &a, int L, bool *used)
 {
   *used = false;
@@ -765,13 +817,10 @@ static int prk_run(ramx_dev *d, const KArgs &a, int L, bool *used)
   PKArgs ka;
   memset(&ka, 0, sizeof(ka));
   int pk_block = 0, pk_blocks = 0;
-  bool pk = !multi && pk_r0 >= 0 && pk_r0 < L && ramx_pk_plan(W, a.go, a.ge, pa.tab, &ka.spread, &ka.rebase) != 0;
-  if (pk)
-  {
-    if ((rc = ramx_pk_shape(W, d->Np / 64, &pk_block, &pk_blocks)) != RAMX_OK) { ramx_set_error("packed-row kernel: occupancy query failed"); return RAMX_ERR_HIP; }
-    if (pk_block == 0 || (pk_r0 > 0 && !int32_can)) pk = false;
-  }
+  bool pk = false;
+  if ((rc = pk_route(d, a, L, multi, int32_can, &pk, &ka.spread, &ka.rebase, &pk_block, &pk_blocks)) != RAMX_OK) return rc;
   if (!pk && !int32_can) { *used = false; return RAMX_OK; }
+  if (!pk && (rc = pack_rest(d)) != RAMX_OK) return rc;        // the int32 kernel reads the whole window
   HIPCHK(hipMemsetAsync(d->d_vote, 0, PRK_NSETS * NSHARD * sizeof(PShard), d->stream));
   HIPCHK(hipMemsetAsync(d->d_err, 0, 64, d->stream));
   long long *sums_next = d->d_sums + (size_t)NSHARD * 4;        // slot 1: zeroed by K(-1)
@@ -795,21 +844,65 @@ static int prk_run(ramx_dev *d, const KArgs &a, int L, bool *used)
   }
   if (rc == RAMX_OK && pk)
   {
-    if (head) HIPCHK(hipMemsetAsync(d->d_vote, 0, PRK_NSETS * NSHARD * sizeof(PShard), d->stream));
     ka.S = d->d_state[0]; ka.bases = d->d_bases; ka.bounds = d->d_bounds; ka.trim = d->d_trim;
-    ka.sums_in = pk_r0 > 0 ? sums_next : d->d_sums; ka.vote = d->d_vote;
-    ka.ctl_in = d->d_ctl; ka.ctl_out = pk_r0 > 0 ? d->d_ctl + 1 : d->d_ctl;      // the first launch's block goes in, the final one out
-    ka.cons_out = d->d_cons; ka.err = d->d_err;
+    ka.vote = d->d_vote; ka.cons_out = d->d_cons; ka.err = d->d_err;
     ka.peers = NULL; ka.box = NULL; ka.mirror = NULL; ka.rank = 0; ka.nranks = 1;
-    ka.Np = d->Np; ka.Nx = d->Nx; ka.r0 = pk_r0; ka.L = L; ka.go = a.go; ka.ge = a.ge; ka.cap = a.cap; ka.minimp = a.minimp;
+    ka.Np = d->Np; ka.Nx = d->Nx; ka.L = L; ka.go = a.go; ka.ge = a.ge; ka.cap = a.cap; ka.minimp = a.minimp;
     ka.when_to_stop = a.when_to_stop; ka.nblocks = pk_blocks;
     memcpy(ka.tab, a.tab, sizeof(ka.tab));
     ka.lean_p = pa.lean_p; ka.leader_max = pa.leader_max;
     ka.spec_on = getenv("RAMX_NO_PK_SPEC") == NULL ? 1 : 0;
     { const char *we = getenv("RAMX_TEST_PK_WRONG_EVERY"); ka.test_wrong_every = we ? atoi(we) : 0; }
-    rc = ramx_pk_launch(d->stream, W, pk_block, pk_blocks, ka);
-    if (rc != RAMX_OK) ramx_set_error("packed-row kernel: launch failed (W %d, %d workgroups of %d threads)", W, pk_blocks, pk_block);
     d->last_packed_r0 = pk_r0;
+    // The direction runs in pieces of RAMX_PK_SEGMENT columns (one launch each: rows written back, sums of the next row handed
+    // over as plain words, control block passed on), so that only the base words a run really reads are ever packed: the
+    // next piece's words are packed on a second stream while this piece runs.
+    const int seg = pk_segment_columns();
+    const int NWw = (2 * W + 1 + 8) / 8 + 2;
+    long long *sbuf[2] = { d->d_sums + (size_t)NSHARD * 4, d->d_sums + (size_t)2 * NSHARD * 4 };     // slots 1 and 2
+    const long long *sums_in = pk_r0 > 0 ? sbuf[0] : d->d_sums;
+    int nextbuf = pk_r0 > 0 ? 1 : 0;
+    int ctl_i = 0;                           // the control block of the launch before sits in d_ctl[ctl_i] (pk_r0 == 0: not read)
+    auto words_for = [&](int r_end) { int wn = ((r_end + 7) >> 3) + NWw + 2; return wn < d->KW ? wn : d->KW; };
+    for (int r = pk_r0, s_i = 0; r < L && rc == RAMX_OK; s_i++)
+    {
+      const int r1 = seg > 0 ? std::min(L, (r / seg + 1) * seg) : L;
+      // this piece's words: normally packed already (begin_direction, or beside the piece before)
+      if (d->pack_busy) { HIPCHK(hipStreamWaitEvent(d->stream, d->pack_done, 0)); d->pack_busy = 0; }
+      if (d->packed_kw < words_for(r1))
+      {
+        if ((rc = launch_pack(d, d->Nx, d->Np, W, d->packed_kw, words_for(r1), d->stream)) != RAMX_OK) break;
+        d->packed_kw = words_for(r1);
+      }
+      HIPCHK(hipMemsetAsync(d->d_vote, 0, PRK_NSETS * NSHARD * sizeof(PShard), d->stream));
+      ka.r0 = r; ka.Lseg = r1; ka.sums_in = sums_in;
+      ka.sums_next = r1 < L ? sbuf[nextbuf] : NULL;
+      if (r1 < L) HIPCHK(hipMemsetAsync(sbuf[nextbuf], 0, (size_t)NSHARD * 4 * sizeof(long long), d->stream));
+      ka.ctl_in = d->d_ctl + ctl_i; ka.ctl_out = d->d_ctl + (ctl_i ^ 1);
+      if (r == 0) ka.ctl_out = d->d_ctl;     // (first launch of the direction: d_ctl[1] still holds K(-1)'s block, nothing is read)
+      rc = ramx_pk_launch(d->stream, W, pk_block, pk_blocks, ka);
+      if (rc != RAMX_OK) { ramx_set_error("packed-row kernel: launch failed (W %d, %d workgroups of %d threads)", W, pk_blocks, pk_block); break; }
+      const int out_i = (r == 0) ? 0 : (ctl_i ^ 1);
+      if (r1 >= L) break;
+      // the next piece's words, beside this launch
+      const int r2 = std::min(L, (r1 / seg + 1) * seg);
+      if (d->packed_kw < words_for(r2))
+      {
+        if ((rc = launch_pack(d, d->Nx, d->Np, W, d->packed_kw, words_for(r2), d->pack_stream)) != RAMX_OK) break;
+        HIPCHK(hipEventRecord(d->pack_done, d->pack_stream));
+        d->pack_busy = 1;
+        d->packed_kw = words_for(r2);
+      }
+      // did this piece end the direction?  (one synchronisation per piece: 2,048 columns)
+      RamxCtl hc;
+      unsigned errw = 0;
+      HIPCHK(hipStreamSynchronize(d->stream));
+      HIPCHK(hipMemcpy(&hc, d->d_ctl + out_i, sizeof(hc), hipMemcpyDeviceToHost));
+      HIPCHK(hipMemcpy(&errw, d->d_err, sizeof(errw), hipMemcpyDeviceToHost));
+      if (hc.stopped || hc.pad != 0 || errw != 0 || hc.rows_done < r1) break;
+      sums_in = sbuf[nextbuf]; nextbuf ^= 1; ctl_i = out_i; r = r1;
+    }
+    // (the caller reads both control blocks and takes the one with more rows)
     if (pk) { block = pk_block; blocks = pk_blocks; }
   }
   else d->last_packed_r0 = -1;
@@ -1057,7 +1150,8 @@ static int run_families_pass(ramx_dev *d, const ramx_flank *flanks, int32_t n_pa
   dfd = (FamDesc *)d->d_fam; dctl = d->d_famctl;
   FAMCHK(hipMemcpyAsync(dfd, hfd, sizeof(FamDesc) * n_families, hipMemcpyHostToDevice, d->stream));
   if (n_padded) FAMCHK(hipMemcpyAsync(d->d_flanks, flanks, (size_t)n_padded * sizeof(ramx_flank), hipMemcpyHostToDevice, d->stream));
-  if ((rc = launch_pack(d, n_padded, Np, KW, W)) != RAMX_OK) goto done;
+  if ((rc = launch_pack(d, n_padded, Np, W, 0, KW, d->stream)) != RAMX_OK) goto done;
+  d->packed_kw = KW;
   FAMCHK(hipMemsetAsync(d->d_cons, 0, (size_t)n_families * (L > 0 ? L : 1) + 16, d->stream));   // columns a family never ran read as 0
   memset(&fa, 0, sizeof(fa));
   fa.bases = d->d_bases; fa.bounds = d->d_bounds; fa.fam = dfd; fa.trim = d->d_trim; fa.ctl_out = dctl; fa.cons_out = d->d_cons;
@@ -1415,6 +1509,29 @@ extern "C" int ramx_dev_run_direction(ramx_dev *d, ramx_run_info *info)
   };
   // Multi-rank: the vote crosses the devices through the mailboxes (ramx_dev_peer_* set-up), exactly as in the
   // lane-per-flank persistent kernel; every rank must take this route or none (one agreement before, one after).
+  // every route but the packed-row one reads base words of the whole window: pack what begin_direction left (pack_rest)
+  {
+    bool lazy = false;
+    if (!tracing && !multi && d->Nx > 0)
+    {
+      int blk = 0, blks = 0, sp = 0, rb = 0, pb = 0, pbs = 0;
+      bool can32 = false;
+      int lrc = prk_local_can(d, a, L, multi, &can32, &blk, &blks);
+      if (lrc != RAMX_OK) return lrc;
+      if ((lrc = pk_route(d, a, L, multi, can32, &lazy, &sp, &rb, &pb, &pbs)) != RAMX_OK) return lrc;
+      // (the device-wide cell-parallel kernel goes first where it applies: it takes the whole window)
+      if (lazy && d->cp_flanks_ok && getenv("RAMX_NO_CP_DEVICE") == NULL && ramx_cp_max_family(a.W, a.go, a.ge, d->tab, L) > 0)
+      {
+        int dev = 0, cus = 0, k = 0, th = 0, nb = 0, vwf = 0;
+        HIPCHK(hipGetDevice(&dev));
+        HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        const char *mx = getenv("RAMX_CP_DEVICE_MAXN");
+        if (mx == NULL || d->Nx <= atoi(mx)) ramx_cp_device_plan(a.W, d->Nx, cus, 0, &k, &th, &nb, &vwf);
+        if (k > 0) lazy = false;
+      }
+    }
+    if (!lazy) { const int prc = pack_rest(d); if (prc != RAMX_OK) return prc; }
+  }
   const bool cp_multi_ok = !multi || (d->peer_ready && d->nranks >= 2 && L < 65536 && getenv("RAMX_NO_PEER") == NULL);
   if (!tracing && cp_multi_ok && !d->force_chain && L > 0 && getenv("RAMX_NO_PERSISTENT") == NULL && getenv("RAMX_NO_CP_DEVICE") == NULL &&
       (multi || d->Nx > 0))
@@ -1613,7 +1730,7 @@ extern "C" int ramx_dev_run_direction(ramx_dev *d, ramx_run_info *info)
     unsigned errw = 0;
     HIPCHK(hipMemcpy(c0, d->d_ctl, sizeof(c0), hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(&errw, d->d_err, sizeof(errw), hipMemcpyDeviceToHost));
-    if (c0[0].pad != 0 || (d->last_packed_r0 > 0 && c0[1].pad != 0) || errw != 0)
+    if (c0[0].pad != 0 || c0[1].pad != 0 || errw != 0)
     {
       if (errw == 2)
         fprintf(stderr, "ramx: the packed-row kernel refused the rows (a cell outside the span computed for this scoring system); repeating "
@@ -1631,6 +1748,7 @@ extern "C" int ramx_dev_run_direction(ramx_dev *d, ramx_run_info *info)
   }
   }
   d->last_persistent = persistent ? 1 : 0;
+  if (!persistent) { const int prc = pack_rest(d); if (prc != RAMX_OK) return prc; }      // the column launches read the whole window
   const int CHUNK = 64;
   const int stride = L > MAX_SAMPLES * 4 ? L / MAX_SAMPLES : 4;
   bool stopped = false;

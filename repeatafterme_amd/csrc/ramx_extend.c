@@ -365,7 +365,7 @@ static int extend_flat_impl(int direction, ramx_flat_cores *c, const int8_t *seq
     info->ret = max_row + 1;
     info->rows_executed = rows_done;
     info->limit_warning = (stopped && rows_done - 1 == L - 1) ? 1 : 0;
-    info->persistent = 0; info->launches = 0; info->lanes_per_flank = 1; info->n_extendable = 0;
+    info->persistent = 1; info->launches = 0; info->lanes_per_flank = 1; info->n_extendable = 0;     /* (no column launches) */
     info->prep_ms = wall_ms() - t0;
     th = (int32_t *)malloc(sizeof(int32_t));
     tp = (int32_t *)malloc(sizeof(int32_t));

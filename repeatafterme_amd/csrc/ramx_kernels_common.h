@@ -57,11 +57,11 @@ struct FamDesc { int tile0, ntiles, nx, id; };      // first 64-flank tile, tile
 // ------------------------------------------------------------------------------------------
 #ifndef RAMX_SECONDARY_TU
 __global__ void ramx_pack_kernel(const signed char *__restrict__ lib, unsigned long long lib_len,
-                                 const ramx_flank *__restrict__ fl, int Nx, int Np, int W,
+                                 const ramx_flank *__restrict__ fl, int Nx, int Np, int W, int k0,
                                  unsigned *__restrict__ bases, int2 *__restrict__ bounds)
 {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  const int k = blockIdx.y;
+  const int k = k0 + blockIdx.y;                 // word k0 .. of every flank's window (the host packs a long window in pieces)
   if (n >= Np) return;
   unsigned word = 0x88888888u;   // class 8 = N everywhere
   if (n < Nx)
@@ -129,7 +129,7 @@ __global__ void ramx_flank_window_kernel(const PkLib L, const ramx_flank *__rest
 }
 
 #define RAMX_PK_WORDS 32
-__global__ void ramx_pack2_kernel(const PkLib L, const ramx_flank *__restrict__ fl, const int *__restrict__ flank_win, int Nx, int Np, int W, int KW,
+__global__ void ramx_pack2_kernel(const PkLib L, const ramx_flank *__restrict__ fl, const int *__restrict__ flank_win, int Nx, int Np, int W, int k0, int KW,
                                   unsigned *__restrict__ bases, int2 *__restrict__ bounds)
 {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
@@ -137,7 +137,7 @@ __global__ void ramx_pack2_kernel(const PkLib L, const ramx_flank *__restrict__ 
   // RAMX_PK_WORDS consecutive words (8 bases each) of one flank per thread: 256 bases are ONE 64-byte line of the payload, so a
   // thread's loads stay in the line it has just brought in (one word per thread, as in ramx_pack_kernel, touches 64 different
   // lines per wavefront for 2-3 bytes each)
-  for (int k = blockIdx.y * RAMX_PK_WORDS; k < (int)(blockIdx.y + 1) * RAMX_PK_WORDS && k < KW; k++)
+  for (int k = k0 + blockIdx.y * RAMX_PK_WORDS; k < k0 + (int)(blockIdx.y + 1) * RAMX_PK_WORDS && k < KW; k++)      // words k0 .. KW-1
   {
   unsigned word = 0x88888888u;   // class 8 = N everywhere
   if (n < Nx)

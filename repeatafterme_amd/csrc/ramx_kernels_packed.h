@@ -341,7 +341,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 256) void ramx_packed_kernel(const P
 
   // ---- stop-rule state and records so far -------------------------------------------------------
   long long max_ext = 0;
-  int max_row = -1, rows_done = a.r0, ovf = 0, stopped = 0, failed = 0;
+  int max_row = -1, rows_done = a.r0, ovf = 0, stopped = 0, failed = 0, carried = 0;
   // the snapshot of the records (ram_extend.c:1203-1207) goes straight to a.trim on every new-maximum column (8 bytes per flank,
   // coalesced): two registers less to carry through the loop
   if (a.r0 > 0)
@@ -356,9 +356,10 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 256) void ramx_packed_kernel(const P
     stopped = (__builtin_amdgcn_readfirstlane(cp->stopped) || rows_done < a.r0) ? 1 : 0;       // the launch before this one stopped (or gave up) early
     const int cpad = __builtin_amdgcn_readfirstlane(cp->pad);
     failed = cpad;
+    carried = __builtin_amdgcn_readfirstlane(cp->besta);       // LEAN rows / rows computed twice so far (0 behind the int32 kernel)
   }
   else if (live) a.trim[n] = make_int2(0, 0);
-  const bool skip = stopped || failed || a.r0 >= a.L;
+  const bool skip = stopped || failed || a.r0 >= a.Lseg;
   if (threadIdx.x == 0) { sm.st[0] = (int)max_ext; sm.st[1] = (int)(max_ext >> 32); sm.st[2] = max_row; sm.st[3] = ovf; }
 
   // ---- row state -> packed registers -----------------------------------------------------------
@@ -425,7 +426,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 256) void ramx_packed_kernel(const P
     if (blockIdx.x == 0 && threadIdx.x == 0)
     {
       RamxCtl o;
-      o.max_ext = max_ext; o.max_row = max_row; o.stopped = stopped; o.rows_done = rows_done; o.overflow = ovf; o.besta = 0; o.pad = failed;
+      o.max_ext = max_ext; o.max_row = max_row; o.stopped = stopped; o.rows_done = rows_done; o.overflow = ovf; o.besta = carried; o.pad = failed;
       *a.ctl_out = o;
     }
     return;
@@ -458,7 +459,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 256) void ramx_packed_kernel(const P
   // workgroup whose sums are all equal (all its flanks at their caps) knows nothing about the winner: it waits for the vote
   // as before, but its LEAN waves have sent their sums before the band, so the exchange runs beside its band as well.
   int spec = 0, guess = 0;               // this column: compute on the workgroup's own argmax before the vote is known
-  for (int r = a.r0; r < a.L; r++)
+  for (int r = a.r0; r < a.Lseg; r++)
   {
     PKB_TICK(5);
     // (the per-thread addresses into the vote sets would live across the whole kernel and find their home in scratch: an opaque
@@ -475,6 +476,9 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 256) void ramx_packed_kernel(const P
       wnext = a.bases[(size_t)kn * a.Np + nn];
     }
     const int par = r & 1, npar = (r + 1) & 1;
+    // the last column of a launch that is not the last of the direction (the host runs a long direction in segments, packing the
+    // base words of the next one meanwhile): its sums go to a.sums_next instead of the vote sets
+    const bool hand_over = r == a.Lseg - 1 && a.Lseg < a.L;
     int besta = 0, next_guess = 0;
     long long dgw = 0;
     bool new_max = false, last_col = false;
@@ -569,8 +573,17 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 256) void ramx_packed_kernel(const P
           if (set == 1)
           {
             asm volatile("ds_write_b64 %0, %1" : : "v"(pkb_lds_off(&sm.tot[set][npar][lane])), "v"(0LL) : "memory");
-            PShard *sh = vb + (size_t)((r + 1) & (PRK_NSETS - 1)) * NSHARD + shard;
-            __hip_atomic_fetch_add(&sh->word[lane], (unsigned long long)t + PRK_BIAS + PRK_TICKET, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (hand_over)     // the launch that continues with row r+1 takes the sums as plain words
+            {
+              int lq = lane;
+              asm volatile("" : "+v"(lq));             // (once per launch: the address is not worth two registers through the loop)
+              __hip_atomic_fetch_add(&a.sums_next[shard * 4 + lq], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            else
+            {
+              PShard *sh = vb + (size_t)((r + 1) & (PRK_NSETS - 1)) * NSHARD + shard;
+              __hip_atomic_fetch_add(&sh->word[lane], (unsigned long long)t + PRK_BIAS + PRK_TICKET, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
           }
         }
         if (set == 1 && lane == 0) asm volatile("ds_write_b32 %0, %1" : : "v"(pkb_lds_off(&sm.cnt[set][npar])), "v"(0) : "memory");
@@ -738,8 +751,17 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 256) void ramx_packed_kernel(const P
           asm volatile("ds_write_b64 %0, %1" : : "v"(pkb_lds_off(&sm.tot[0][npar][lane])), "v"(0LL) : "memory");
           if (right && !last_col)
           {
-            PShard *sh = vb + (size_t)((r + 1) & (PRK_NSETS - 1)) * NSHARD + shard;
-            __hip_atomic_fetch_add(&sh->word[lane], (unsigned long long)t + PRK_BIAS + PRK_TICKET, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (hand_over)
+            {
+              int lq = lane;
+              asm volatile("" : "+v"(lq));
+              __hip_atomic_fetch_add(&a.sums_next[shard * 4 + lq], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            else
+            {
+              PShard *sh = vb + (size_t)((r + 1) & (PRK_NSETS - 1)) * NSHARD + shard;
+              __hip_atomic_fetch_add(&sh->word[lane], (unsigned long long)t + PRK_BIAS + PRK_TICKET, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
           }
         }
         if (lane == 0) asm volatile("ds_write_b32 %0, %1" : : "v"(pkb_lds_off(&sm.cnt[0][npar])), "v"(0) : "memory");
@@ -766,7 +788,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 256) void ramx_packed_kernel(const P
       asm volatile("" : "+v"(nn));
       a.trim[nn] = make_int2(high, pos);
     }
-    if (last_col) break;
+    if (last_col || hand_over) break;
     // next column: the guess its totals gave.  After a confirmed round the last arriver wrote it just now: one more barrier makes
     // it (and the cleared totals) everybody's; after a guess that stood, the barrier of decide() has done so already
     if constexpr (SPEC)
@@ -785,9 +807,9 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 256) void ramx_packed_kernel(const P
   if (a.dbg != NULL && (threadIdx.x & 63) == 0)
   {
 #pragma unroll
-    for (int k = 0; k < 6; k++) a.dbg[((size_t)blockIdx.x * WPB + wave) * 8 + k] = tsum[k];
-    a.dbg[((size_t)blockIdx.x * WPB + wave) * 8 + 6] = (unsigned long long)full_rows;
-    a.dbg[((size_t)blockIdx.x * WPB + wave) * 8 + 7] = (unsigned long long)lean_rows;
+    for (int k = 0; k < 6; k++) a.dbg[((size_t)blockIdx.x * WPB + wave) * 8 + k] += tsum[k];      // (+=: a direction is several launches)
+    a.dbg[((size_t)blockIdx.x * WPB + wave) * 8 + 6] += (unsigned long long)full_rows;
+    a.dbg[((size_t)blockIdx.x * WPB + wave) * 8 + 7] += (unsigned long long)lean_rows;
   }
 #endif
 
@@ -825,7 +847,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 256) void ramx_packed_kernel(const P
     RamxCtl o;
     o.max_ext = ((long long)sm.st[1] << 32) | (long long)(unsigned)sm.st[0]; o.max_row = sm.st[2]; o.stopped = stopped; o.rows_done = rows_done;
     o.overflow = sm.st[3];
-    o.besta = lean_rows | (wrong_rows << 16);      // reported: LEAN rows of the first wave, rows it computed twice after a wrong guess
+    o.besta = ((carried & 0xffff) + lean_rows) | ((((carried >> 16) & 0xffff) + wrong_rows) << 16);      // reported: LEAN rows of the first wave, rows it computed twice after a wrong guess
     o.pad = failed;
     *a.ctl_out = o;
   }

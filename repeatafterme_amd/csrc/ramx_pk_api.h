@@ -25,7 +25,8 @@ struct PKArgs
   PeerBox *box;
   PeerBox *mirror;
   int rank, nranks;
-  int Np, Nx, r0, L, go, ge, cap, minimp, when_to_stop, nblocks;
+  long long *sums_next;         // Lseg < L: the sums of row Lseg as NSHARD x 4 plain int64 words (zeroed by the host) for the launch that continues
+  int Np, Nx, r0, Lseg, L, go, ge, cap, minimp, when_to_stop, nblocks;      // this launch runs rows r0 .. Lseg-1 of a direction of L rows
   int tab[RAMX_NCLASS][4];
   int lean_p;                   // P = max(0, largest matrix entry) of the LEAN test; -1: never LEAN
   int leader_max;               // a wave with at most this many lanes that fail the LEAN test runs LEAN + pkb_leader_rows (0: off)

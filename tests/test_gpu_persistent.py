@@ -259,3 +259,32 @@ def test_packed_rows_speculation_rolls_back_exactly(W, matrix, monkeypatch):
                 assert np.array_equal(ca, cb) and (ha, pa) == (hb, pb), (every, kw)
             if every in ("1", "2", "3"):
                 assert got[0].respeculated_rows > 0, (every, kw)          # the hook really makes rows run twice
+
+
+@pytest.mark.parametrize("seg", ["16", "50", "128"])
+def test_packed_rows_direction_in_pieces(seg, monkeypatch):
+    """A long direction runs as several launches of the packed-row kernel (RAMX_PK_SEGMENT columns each; 2,048 by default): rows go
+    back to HBM, the sums of the next row are handed over as plain words, the control block is passed on, and only the base words
+    a piece reads are packed (the next piece's beside the running one).  With pieces of 16 / 50 / 128 columns -- boundaries in
+    the aligned phase, in the LEAN phase, at the stop row, at rebase rows -- results and final DP rows equal a one-piece run and
+    the oracle."""
+    import os
+    if not os.environ.get("RAMX_NO_CP_DEVICE"):
+        pytest.skip("the lane-per-flank route is selected by the fixture's RAMX_NO_CP_DEVICE leg")
+    W, L = 40, 760
+    fs = _two_copy_family(900, L, W, 100, seed=6100, short_frac=0.05)
+    for kw in (dict(when_to_stop=L), dict(when_to_stop=40)):
+        p = po.Params.named("14p43g", bandwidth=W, L=L, **kw)
+        monkeypatch.setenv("RAMX_PK_SEGMENT", "0")
+        ref = _run_device(fs, p, 1, monkeypatch, True)
+        monkeypatch.setenv("RAMX_PK_SEGMENT", seg)
+        got = _run_device(fs, p, 1, monkeypatch, True)
+        x = run_both_directions(oracle_extend, fs.cores, fs.sequence, p)
+        y = run_both_directions(gpu_extend, fs.cores, fs.sequence, p)
+        monkeypatch.delenv("RAMX_PK_SEGMENT")
+        assert_same_result(x[0], x[1], x[2:], y[0], y[1], y[2:], f"seg={seg} {kw}")
+        assert ref[0].packed_rows > 0 and got[0].packed_rows == ref[0].packed_rows
+        assert (got[0].ret, got[0].rows_executed, got[0].limit_warning) == (ref[0].ret, ref[0].rows_executed, ref[0].limit_warning)
+        assert np.array_equal(got[1], ref[1]) and np.array_equal(got[2], ref[2]) and np.array_equal(got[3], ref[3])
+        for (ca, ha, pa), (cb, hb, pb) in zip(got[4], ref[4]):
+            assert np.array_equal(ca, cb) and (ha, pa) == (hb, pb)
