@@ -195,6 +195,8 @@ static void *warm_device(void *unused)
 {
   (void)unused;
   (void)ramx_default_device();          /* failure is reported by the main thread's own call later */
+  /* (Loading the code objects here as well -- ramx_dev_warm -- was measured and dropped: the runtime's start-up already takes as
+   * long as the loader does, the main thread then WAITS for this thread (20-100 ms), and the first launches were no faster.) */
   pthread_mutex_lock(&g_warm_mu);
   while (g_warm_lib == NULL && !g_warm_quit) pthread_cond_wait(&g_warm_cv, &g_warm_mu);
   const struct sequenceLibrary *lib = g_warm_lib;

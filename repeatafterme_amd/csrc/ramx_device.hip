@@ -104,6 +104,7 @@ struct ramx_dev
   size_t cap_flanks, cap_bases, cap_state, cap_cons, cap_bounds, cap_trim, cap_fam, cap_famctl;
   void *d_fam; RamxCtl *d_famctl;    // batch mode: family descriptors / per-family control blocks (kept between calls)
   RamxCtl *h_ctl;   // pinned, [2 checkpoints][2 slots]
+  void *h_stage; size_t cap_stage;   // pinned staging buffer of ramx_dev_download (a pageable 800 KB copy took 8 ms)
   hipEvent_t ev_chk[2], ev_begin, ev_end, ev_s0[MAX_SAMPLES], ev_s1[MAX_SAMPLES];
   int Nx, Np, KW;
   ramx_params p; int tab[RAMX_NCLASS][4];
@@ -165,6 +166,10 @@ extern "C" int ramx_dev_create(int ordinal, ramx_dev **out)
   CRCHK(hipStreamCreateWithFlags(&d->pack_stream, hipStreamNonBlocking));
   CRCHK(hipEventCreateWithFlags(&d->pack_done, hipEventDisableTiming));
   CRCHK(hipHostMalloc((void **)&d->h_ctl, 4 * sizeof(RamxCtl), hipHostMallocDefault));
+  // staging buffer of ramx_dev_download: allocated here (pinning takes milliseconds; the executable creates the session in its
+  // helper thread), 2 MB = 262,144 flanks, grown on demand
+  CRCHK(hipHostMalloc(&d->h_stage, (size_t)2 << 20, hipHostMallocDefault));
+  d->cap_stage = (size_t)2 << 20;
   CRCHK(hipMalloc((void **)&d->d_sums, (3 * NSHARD * 4 + 8) * sizeof(long long)));
   CRCHK(hipMalloc((void **)&d->d_ctl, 2 * sizeof(RamxCtl)));
   CRCHK(hipMalloc((void **)&d->d_vote, PRK_NSETS * NSHARD * sizeof(PShard)));   // four rotating vote sets (both persistent kernels)
@@ -198,6 +203,7 @@ extern "C" void ramx_dev_destroy(ramx_dev *d)
   (void)hipFree(d->d_state[0]); if (d->d_state[1] != d->d_state[0]) (void)hipFree(d->d_state[1]); (void)hipFree(d->d_trim); (void)hipFree(d->d_sums);
   (void)hipFree(d->d_ctl); (void)hipFree(d->d_cons); (void)hipFree(d->d_vote); (void)hipFree(d->d_err);
   if (d->h_ctl) (void)hipHostFree(d->h_ctl);
+  if (d->h_stage) (void)hipHostFree(d->h_stage);
   if (d->hostbox_map)
   {
     if (d->hostbox_registered) (void)hipHostUnregister(d->hostbox_map);
@@ -637,12 +643,15 @@ static int lean_p_of(const int (&tab)[RAMX_NCLASS][4], int go, int ge)
 template <int W, int BLOCK>
 static int prk_capacity_blocks(int *out)
 {
+  static int cached = -1;              // (one device per process; the query is a runtime call per direction otherwise)
+  if (cached >= 0) { *out = cached; return RAMX_OK; }
   int per_cu = 0, dev = 0, cus = 0;
   HIPCHK(hipGetDevice(&dev));
   HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
   HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ramx_persistent_kernel<W, BLOCK>, BLOCK, 0));
   if (per_cu > 1) per_cu = 1;          // one block per CU by design; never trust the API for more
   *out = per_cu * cus;
+  cached = *out;
   return RAMX_OK;
 }
 
@@ -834,6 +843,8 @@ static int prk_run(ramx_dev *d, const KArgs &a, int L, bool *used)
   if (pk) ka.dbg = dbgbuf; else pa.dbg = dbgbuf;                 // timing build: with a packed launch, its phases are the ones printed
 #endif
   rc = RAMX_OK;
+  const bool tmarks = getenv("RAMX_TIMING") != NULL;
+  const double tm0 = now_ms();
   if (head)
   {
     if (block == 256)
@@ -880,8 +891,10 @@ static int prk_run(ramx_dev *d, const KArgs &a, int L, bool *used)
       if (r1 < L) HIPCHK(hipMemsetAsync(sbuf[nextbuf], 0, (size_t)NSHARD * 4 * sizeof(long long), d->stream));
       ka.ctl_in = d->d_ctl + ctl_i; ka.ctl_out = d->d_ctl + (ctl_i ^ 1);
       if (r == 0) ka.ctl_out = d->d_ctl;     // (first launch of the direction: d_ctl[1] still holds K(-1)'s block, nothing is read)
+      const double tm1 = now_ms();
       rc = ramx_pk_launch(d->stream, W, pk_block, pk_blocks, ka);
       if (rc != RAMX_OK) { ramx_set_error("packed-row kernel: launch failed (W %d, %d workgroups of %d threads)", W, pk_blocks, pk_block); break; }
+      if (tmarks) fprintf(stderr, "RAMX_TIMING       run: piece %d (rows %d..%d) launched %.3f ms after the first launch (launch call %.3f ms)\n", s_i, r, r1, now_ms() - tm0, now_ms() - tm1);
       const int out_i = (r == 0) ? 0 : (ctl_i ^ 1);
       if (r1 >= L) break;
       // the next piece's words, beside this launch
@@ -897,6 +910,7 @@ static int prk_run(ramx_dev *d, const KArgs &a, int L, bool *used)
       RamxCtl hc;
       unsigned errw = 0;
       HIPCHK(hipStreamSynchronize(d->stream));
+      if (tmarks) fprintf(stderr, "RAMX_TIMING       run: piece %d complete %.3f ms after the first launch\n", s_i, now_ms() - tm0);
       HIPCHK(hipMemcpy(&hc, d->d_ctl + out_i, sizeof(hc), hipMemcpyDeviceToHost));
       HIPCHK(hipMemcpy(&errw, d->d_err, sizeof(errw), hipMemcpyDeviceToHost));
       if (hc.stopped || hc.pad != 0 || errw != 0 || hc.rows_done < r1) break;
@@ -1847,6 +1861,8 @@ extern "C" int ramx_dev_download(ramx_dev *d, int8_t *cons, int32_t cons_cap, in
   if (!d || !d->ready) { ramx_set_error("ramx_dev_download: nothing to download"); return RAMX_ERR_STATE; }
   HIPCHK(hipSetDevice(d->ordinal));
   const int rows = d->final_ctl.rows_done;
+  const bool timing = getenv("RAMX_TIMING") != NULL;
+  const double td0 = now_ms();
   if (cons)
   {
     if (cons_cap < rows) { ramx_set_error("cons buffer too small (%d < %d)", cons_cap, rows); return RAMX_ERR_ARG; }
@@ -1854,14 +1870,26 @@ extern "C" int ramx_dev_download(ramx_dev *d, int8_t *cons, int32_t cons_cap, in
   }
   if ((trim_high || trim_pos) && d->Nx)
   {
-    int2 *tmp = (int2 *)malloc((size_t)d->Nx * sizeof(int2));
-    HIPCHK(hipMemcpy(tmp, d->d_trim, (size_t)d->Nx * sizeof(int2), hipMemcpyDeviceToHost));
+    // through a pinned buffer kept with the session: the copy into pageable memory pins the caller's pages on the fly (8 ms for
+    // 800 KB at N = 100,000)
+    const size_t need = (size_t)d->Nx * sizeof(int2);
+    if (need > d->cap_stage)
+    {
+      if (d->h_stage) HIPCHK(hipHostFree(d->h_stage));
+      d->h_stage = NULL; d->cap_stage = 0;
+      HIPCHK(hipHostMalloc(&d->h_stage, need + need / 2, hipHostMallocDefault));
+      d->cap_stage = need + need / 2;
+    }
+    int2 *tmp = (int2 *)d->h_stage;
+    const double td1 = now_ms();
+    HIPCHK(hipMemcpyAsync(tmp, d->d_trim, need, hipMemcpyDeviceToHost, d->stream));
+    HIPCHK(hipStreamSynchronize(d->stream));
+    if (timing) fprintf(stderr, "RAMX_TIMING       download: consensus %.3f ms, trim copy %.3f ms\n", td1 - td0, now_ms() - td1);
     for (int i = 0; i < d->Nx; i++)
     {
       if (trim_high) trim_high[i] = tmp[i].x;
       if (trim_pos) trim_pos[i] = tmp[i].y;
     }
-    free(tmp);
   }
   return RAMX_OK;
 }

@@ -32,12 +32,15 @@ int ramx_pk_plan(int W, int go, int ge, const int (&tab)[RAMX_NCLASS][4], int *s
 template <int W, int BLOCK>
 static int pk_capacity(int *out)
 {
+  static int cached = -1;              // (one device per process)
+  if (cached >= 0) { *out = cached; return RAMX_OK; }
   int per_cu = 0, dev = 0, cus = 0;
   if (hipGetDevice(&dev) != hipSuccess) return RAMX_ERR_HIP;
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return RAMX_ERR_HIP;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ramx_packed_kernel<W, BLOCK>, BLOCK, 0) != hipSuccess) return RAMX_ERR_HIP;
   if (per_cu > 1) per_cu = 1;          // one workgroup per CU by design (one barrier participant per CU)
   *out = per_cu * cus;
+  cached = *out;
   return RAMX_OK;
 }
 
