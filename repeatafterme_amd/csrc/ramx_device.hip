@@ -74,6 +74,18 @@ extern "C" const char *ramx_last_error(void) { return g_err; }
     }                                                                                             \
   } while (0)
 
+static double now_ms(void);
+// RAMX_TIMING: host-side marks inside a direction (ms since the mark before)
+static void rt_mark(const char *what)
+{
+  static double last = 0;
+  static int on = -1;
+  if (on < 0) on = getenv("RAMX_TIMING") != NULL;
+  if (!on) return;
+  const double t = now_ms();
+  if (what) fprintf(stderr, "RAMX_TIMING       run: %-44s %8.3f ms\n", what, t - last);
+  last = t;
+}
 static double now_ms(void)
 {
   struct timespec ts;
@@ -845,6 +857,7 @@ static int prk_run(ramx_dev *d, const KArgs &a, int L, bool *used)
   rc = RAMX_OK;
   const bool tmarks = getenv("RAMX_TIMING") != NULL;
   const double tm0 = now_ms();
+  rt_mark("persistent route, memsets");
   if (head)
   {
     if (block == 256)
@@ -853,6 +866,7 @@ static int prk_run(ramx_dev *d, const KArgs &a, int L, bool *used)
     else
       rc = (W == 14) ? prk_launch<14, 512>(d, pa, blocks) : (W == 20) ? prk_launch<20, 512>(d, pa, blocks) : prk_launch<40, 512>(d, pa, blocks);
   }
+  rt_mark("first rows launched (int32 kernel)");
   if (rc == RAMX_OK && pk)
   {
     ka.S = d->d_state[0]; ka.bases = d->d_bases; ka.bounds = d->d_bounds; ka.trim = d->d_trim;
@@ -894,7 +908,7 @@ static int prk_run(ramx_dev *d, const KArgs &a, int L, bool *used)
       const double tm1 = now_ms();
       rc = ramx_pk_launch(d->stream, W, pk_block, pk_blocks, ka);
       if (rc != RAMX_OK) { ramx_set_error("packed-row kernel: launch failed (W %d, %d workgroups of %d threads)", W, pk_blocks, pk_block); break; }
-      if (tmarks) fprintf(stderr, "RAMX_TIMING       run: piece %d (rows %d..%d) launched %.3f ms after the first launch (launch call %.3f ms)\n", s_i, r, r1, now_ms() - tm0, now_ms() - tm1);
+      if (tmarks) fprintf(stderr, "RAMX_TIMING       run: piece %d (rows %d..%d, %d x %d threads) launched %.3f ms after the first launch (launch call %.3f ms)\n", s_i, r, r1, pk_blocks, pk_block, now_ms() - tm0, now_ms() - tm1);
       const int out_i = (r == 0) ? 0 : (ctl_i ^ 1);
       if (r1 >= L) break;
       // the next piece's words, beside this launch
@@ -1524,6 +1538,7 @@ extern "C" int ramx_dev_run_direction(ramx_dev *d, ramx_run_info *info)
   // Multi-rank: the vote crosses the devices through the mailboxes (ramx_dev_peer_* set-up), exactly as in the
   // lane-per-flank persistent kernel; every rank must take this route or none (one agreement before, one after).
   // every route but the packed-row one reads base words of the whole window: pack what begin_direction left (pack_rest)
+  rt_mark(NULL);
   {
     bool lazy = false;
     if (!tracing && !multi && d->Nx > 0)
@@ -1546,6 +1561,7 @@ extern "C" int ramx_dev_run_direction(ramx_dev *d, ramx_run_info *info)
     }
     if (!lazy) { const int prc = pack_rest(d); if (prc != RAMX_OK) return prc; }
   }
+  rt_mark("route (occupancy answers)");
   const bool cp_multi_ok = !multi || (d->peer_ready && d->nranks >= 2 && L < 65536 && getenv("RAMX_NO_PEER") == NULL);
   if (!tracing && cp_multi_ok && !d->force_chain && L > 0 && getenv("RAMX_NO_PERSISTENT") == NULL && getenv("RAMX_NO_CP_DEVICE") == NULL &&
       (multi || d->Nx > 0))
@@ -1675,6 +1691,7 @@ extern "C" int ramx_dev_run_direction(ramx_dev *d, ramx_run_info *info)
     }
   }
   const bool cp_done = persistent;
+  rt_mark("cell-parallel plan / launch");
   if (!cp_done)
   {
   HIPCHK(hipMemsetAsync(d->d_sums, 0, 3 * NSHARD * 4 * sizeof(long long), d->stream));
@@ -1693,6 +1710,7 @@ extern "C" int ramx_dev_run_direction(ramx_dev *d, ramx_run_info *info)
   }
   else launch_column<true>(d, a);
   HIPCHK(hipGetLastError());
+  rt_mark("boundary row launched");
   {
     // the in-place row buffer holds S(-1) after K(-1); d_ctl[1] holds the initial control block, the persistent
     // kernel writes its final one to d_ctl[0]
@@ -1817,9 +1835,11 @@ extern "C" int ramx_dev_run_direction(ramx_dev *d, ramx_run_info *info)
     }
   }
   if (!cp_done) HIPCHK(hipEventRecord(d->ev_end, d->stream));
+  rt_mark("loop enqueued / pieces run");
   HIPCHK(hipStreamSynchronize(d->stream));
   RamxCtl h[2];
   HIPCHK(hipMemcpy(h, d->d_ctl, sizeof(h), hipMemcpyDeviceToHost));
+  rt_mark("final synchronisation, control blocks");
   const RamxCtl &f = (L == 0) ? h[1] : ((h[0].rows_done > h[1].rows_done) ? h[0] : h[1]);
   d->final_ctl = f;
   if (persistent)
@@ -1882,7 +1902,13 @@ extern "C" int ramx_dev_download(ramx_dev *d, int8_t *cons, int32_t cons_cap, in
     }
     int2 *tmp = (int2 *)d->h_stage;
     const double td1 = now_ms();
-    HIPCHK(hipMemcpyAsync(tmp, d->d_trim, need, hipMemcpyDeviceToHost, d->stream));
+    if (getenv("RAMX_DOWNLOAD_DMA"))
+      HIPCHK(hipMemcpyAsync(tmp, d->d_trim, need, hipMemcpyDeviceToHost, d->stream));
+    else
+    {
+      hipLaunchKernelGGL(ramx_to_host_kernel, dim3((d->Nx + 255) / 256), dim3(256), 0, d->stream, (const int2 *)d->d_trim, tmp, d->Nx);
+      HIPCHK(hipGetLastError());
+    }
     HIPCHK(hipStreamSynchronize(d->stream));
     if (timing) fprintf(stderr, "RAMX_TIMING       download: consensus %.3f ms, trim copy %.3f ms\n", td1 - td0, now_ms() - td1);
     for (int i = 0; i < d->Nx; i++)

@@ -117,6 +117,14 @@ __device__ __forceinline__ int pk_window_of(const PkLib &L, unsigned long long p
 
 // window of every flank's first base (its other bases lie in the same window unless the caller's bounds say otherwise:
 // ramx_pack2_kernel looks again for those)
+// the trim records of a finished direction, written straight into the session's pinned host buffer: the first device-to-host DMA
+// of a process costs about 6 ms of engine set-up on this stack, a store over the bus from a kernel that is already loaded none
+__global__ void ramx_to_host_kernel(const int2 *__restrict__ src, int2 *__restrict__ dst, int n)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[i];
+}
+
 __global__ void ramx_flank_window_kernel(const PkLib L, const ramx_flank *__restrict__ fl, int Nx, int *__restrict__ flank_win)
 {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;

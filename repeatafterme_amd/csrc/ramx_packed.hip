@@ -38,7 +38,13 @@ static int pk_capacity(int *out)
   if (hipGetDevice(&dev) != hipSuccess) return RAMX_ERR_HIP;
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return RAMX_ERR_HIP;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ramx_packed_kernel<W, BLOCK>, BLOCK, 0) != hipSuccess) return RAMX_ERR_HIP;
-  if (per_cu > 1) per_cu = 1;          // one workgroup per CU by design (one barrier participant per CU)
+  // One workgroup per CU (one barrier participant per CU).  Two 256-thread workgroups per CU instead of one of 512 threads (each
+  // with one wave per SIMD, drifting apart so that one's barriers fall into the other's band; RAMX_PK_WG_PER_CU=2) were measured
+  // at the bench size: aligned phase 7.12 against 7.14 us per column, capped tail 5.70 against 5.53 -- twice the tickets per vote
+  // cost more than the drift gave (profiles/r04_notes.md)
+  int lim = 1;
+  if (const char *e = getenv("RAMX_PK_WG_PER_CU")) lim = atoi(e) >= 2 && BLOCK == 256 ? 2 : 1;
+  if (per_cu > lim) per_cu = lim;
   *out = per_cu * cus;
   cached = *out;
   return RAMX_OK;
@@ -51,6 +57,7 @@ static int pk_shape(int tiles, int *block, int *blocks)
   *block = 0; *blocks = 0;
   // one wave per SIMD while the flank set allows it, two above
   if ((rc = pk_capacity<W, 256>(&cap)) != RAMX_OK) return rc;
+  if (getenv("RAMX_PK_NO_256") != NULL) cap = 0;
   if ((tiles + 3) / 4 <= cap) { *block = 256; *blocks = (tiles + 3) / 4; return RAMX_OK; }
   if constexpr (W <= 40)       // W = 80: 162 row registers leave no room for a second wave per SIMD (it would run from scratch memory)
   {
