@@ -724,6 +724,30 @@ static bool prk_has_width(int W) { return W == 14 || W == 20 || W == 40 || W == 
 static bool fam_has_width(int W) { return W == 14 || W == 20 || W == 40; }
 
 // this rank's own answer to "can the lane-per-flank persistent kernel run this direction", and its launch shape
+// A few words from device memory to the host at the end of a launch (control blocks, the error word, the consensus): written by
+// a kernel into the session's pinned buffer.  hipMemcpy would do, but the first device-to-host copy of a process costs
+// milliseconds of DMA set-up on this stack (6-10 ms of a 33 ms direction at N = 100,000), a store over the bus none.
+// At most 64 KB (the tail of the staging buffer; the trim records use its head); the kernel moves whole 8-byte words (a source
+// that is not a multiple of 8 bytes is over-read by up to 7 bytes, inside its allocation's granule).
+static int d2h_small(ramx_dev *d, void *dst, const void *src, size_t bytes)
+{
+  const size_t off = d->cap_stage - ((size_t)64 << 10);
+  if (bytes == 0) return RAMX_OK;
+  if (bytes > ((size_t)64 << 10) || d->h_stage == NULL || d->cap_stage < ((size_t)128 << 10) || getenv("RAMX_DOWNLOAD_DMA") != NULL)
+  {
+    HIPCHK(hipStreamSynchronize(d->stream));
+    HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return RAMX_OK;
+  }
+  int2 *stage = (int2 *)((char *)d->h_stage + off);
+  const int n = (int)((bytes + 7) / 8);
+  hipLaunchKernelGGL(ramx_to_host_kernel, dim3((n + 255) / 256), dim3(256), 0, d->stream, (const int2 *)src, stage, n);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(d->stream));
+  memcpy(dst, stage, bytes);
+  return RAMX_OK;
+}
+
 static int prk_local_can(ramx_dev *d, const KArgs &a, int L, bool multi, bool *can_out, int *block, int *blocks)
 {
   const int W = a.W;
@@ -751,7 +775,10 @@ static int pk_route(ramx_dev *d, const KArgs &a, int L, bool multi, bool int32_c
 {
   *pk_out = false; *pk_block = 0; *pk_blocks = 0;
   const int pk_r0 = (getenv("RAMX_NO_PERSISTENT") != NULL || d->force_chain || L <= 0) ? -1 : d->pk_r0;
-  bool pk = !multi && pk_r0 >= 0 && pk_r0 < L && ramx_pk_plan(a.W, a.go, a.ge, a.tab, spread, rebase) != 0;
+  // (multi-rank: the packed kernel speaks the same mailbox protocol as the int32 one, ramx_kernels_vote.h; which of the two a rank
+  // runs, from which row on and in how many pieces is that rank's own business)
+  bool pk = pk_r0 >= 0 && pk_r0 < L && ramx_pk_plan(a.W, a.go, a.ge, a.tab, spread, rebase) != 0;
+  if (multi && (!d->peer_ready || d->nranks < 2 || L >= 65536 || getenv("RAMX_NO_PEER") != NULL || getenv("RAMX_NO_PK_MULTI") != NULL)) pk = false;
   if (pk)
   {
     if (ramx_pk_shape(a.W, d->Np / 64, pk_block, pk_blocks) != RAMX_OK) { ramx_set_error("packed-row kernel: occupancy query failed"); return RAMX_ERR_HIP; }
@@ -871,7 +898,7 @@ static int prk_run(ramx_dev *d, const KArgs &a, int L, bool *used)
   {
     ka.S = d->d_state[0]; ka.bases = d->d_bases; ka.bounds = d->d_bounds; ka.trim = d->d_trim;
     ka.vote = d->d_vote; ka.cons_out = d->d_cons; ka.err = d->d_err;
-    ka.peers = NULL; ka.box = NULL; ka.mirror = NULL; ka.rank = 0; ka.nranks = 1;
+    ka.peers = pa.peers; ka.box = pa.box; ka.mirror = pa.mirror; ka.rank = pa.rank; ka.nranks = pa.nranks;
     ka.Np = d->Np; ka.Nx = d->Nx; ka.L = L; ka.go = a.go; ka.ge = a.ge; ka.cap = a.cap; ka.minimp = a.minimp;
     ka.when_to_stop = a.when_to_stop; ka.nblocks = pk_blocks;
     memcpy(ka.tab, a.tab, sizeof(ka.tab));
@@ -889,6 +916,7 @@ static int prk_run(ramx_dev *d, const KArgs &a, int L, bool *used)
     int nextbuf = pk_r0 > 0 ? 1 : 0;
     int ctl_i = 0;                           // the control block of the launch before sits in d_ctl[ctl_i] (pk_r0 == 0: not read)
     auto words_for = [&](int r_end) { int wn = ((r_end + 7) >> 3) + NWw + 2; return wn < d->KW ? wn : d->KW; };
+    if (ka.nranks > 1 && !head) test_delay_rank(d);
     for (int r = pk_r0, s_i = 0; r < L && rc == RAMX_OK; s_i++)
     {
       const int r1 = seg > 0 ? std::min(L, (r / seg + 1) * seg) : L;
@@ -925,8 +953,13 @@ static int prk_run(ramx_dev *d, const KArgs &a, int L, bool *used)
       unsigned errw = 0;
       HIPCHK(hipStreamSynchronize(d->stream));
       if (tmarks) fprintf(stderr, "RAMX_TIMING       run: piece %d complete %.3f ms after the first launch\n", s_i, now_ms() - tm0);
-      HIPCHK(hipMemcpy(&hc, d->d_ctl + out_i, sizeof(hc), hipMemcpyDeviceToHost));
-      HIPCHK(hipMemcpy(&errw, d->d_err, sizeof(errw), hipMemcpyDeviceToHost));
+      {
+        unsigned long long ew = 0;
+        if ((rc = d2h_small(d, &hc, d->d_ctl + out_i, sizeof(hc))) != RAMX_OK) break;
+        if ((rc = d2h_small(d, &ew, d->d_err, sizeof(ew))) != RAMX_OK) break;
+        errw = (unsigned)ew;
+      }
+      rt_mark("piece: control block and error word read");
       if (hc.stopped || hc.pad != 0 || errw != 0 || hc.rows_done < r1) break;
       sums_in = sbuf[nextbuf]; nextbuf ^= 1; ctl_i = out_i; r = r1;
     }
@@ -1730,14 +1763,17 @@ extern "C" int ramx_dev_run_direction(ramx_dev *d, ramx_run_info *info)
     // agree over all ranks whether the cross-device launch went through; if any rank gave up (bounded spin) or failed
     // locally, every rank repeats the direction with the per-column launches and the host collective
     int bad = prk_local_rc != RAMX_OK;
-    RamxCtl c0;
-    memset(&c0, 0, sizeof(c0));
+    RamxCtl c0[2];
+    unsigned errw = 0;
+    memset(c0, 0, sizeof(c0));
     if (!bad)
     {
-      if (hipStreamSynchronize(d->stream) != hipSuccess || hipMemcpy(&c0, d->d_ctl, sizeof(c0), hipMemcpyDeviceToHost) != hipSuccess) bad = 1;
+      // (both control blocks: a direction that ran in pieces leaves its last one in either; the error word: a refused entry check)
+      if (hipStreamSynchronize(d->stream) != hipSuccess || hipMemcpy(c0, d->d_ctl, sizeof(c0), hipMemcpyDeviceToHost) != hipSuccess ||
+          hipMemcpy(&errw, d->d_err, sizeof(errw), hipMemcpyDeviceToHost) != hipSuccess) bad = 1;
     }
     else (void)hipStreamSynchronize(d->stream);
-    bad = bad || c0.pad != 0;
+    bad = bad || c0[0].pad != 0 || c0[1].pad != 0 || errw != 0;
     int frc = host_allreduce_flag(d, &bad);
     if (frc != RAMX_OK) return frc;
     if (bad)
@@ -1760,8 +1796,14 @@ extern "C" int ramx_dev_run_direction(ramx_dev *d, ramx_run_info *info)
     HIPCHK(hipStreamSynchronize(d->stream));
     RamxCtl c0[2];
     unsigned errw = 0;
-    HIPCHK(hipMemcpy(c0, d->d_ctl, sizeof(c0), hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(&errw, d->d_err, sizeof(errw), hipMemcpyDeviceToHost));
+    {
+      unsigned long long ew = 0;
+      int drc;
+      if ((drc = d2h_small(d, c0, d->d_ctl, sizeof(c0))) != RAMX_OK) return drc;
+      if ((drc = d2h_small(d, &ew, d->d_err, sizeof(ew))) != RAMX_OK) return drc;
+      errw = (unsigned)ew;
+    }
+    rt_mark("after the launch: control blocks, error word");
     if (c0[0].pad != 0 || c0[1].pad != 0 || errw != 0)
     {
       if (errw == 2)
@@ -1838,7 +1880,7 @@ extern "C" int ramx_dev_run_direction(ramx_dev *d, ramx_run_info *info)
   rt_mark("loop enqueued / pieces run");
   HIPCHK(hipStreamSynchronize(d->stream));
   RamxCtl h[2];
-  HIPCHK(hipMemcpy(h, d->d_ctl, sizeof(h), hipMemcpyDeviceToHost));
+  { const int drc = d2h_small(d, h, d->d_ctl, sizeof(h)); if (drc != RAMX_OK) return drc; }
   rt_mark("final synchronisation, control blocks");
   const RamxCtl &f = (L == 0) ? h[1] : ((h[0].rows_done > h[1].rows_done) ? h[0] : h[1]);
   d->final_ctl = f;
@@ -1886,7 +1928,7 @@ extern "C" int ramx_dev_download(ramx_dev *d, int8_t *cons, int32_t cons_cap, in
   if (cons)
   {
     if (cons_cap < rows) { ramx_set_error("cons buffer too small (%d < %d)", cons_cap, rows); return RAMX_ERR_ARG; }
-    if (rows) HIPCHK(hipMemcpy(cons, d->d_cons, (size_t)rows, hipMemcpyDeviceToHost));
+    if (rows) { const int drc = d2h_small(d, cons, d->d_cons, (size_t)rows); if (drc != RAMX_OK) return drc; }
   }
   if ((trim_high || trim_pos) && d->Nx)
   {

@@ -500,7 +500,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 256) void ramx_packed_kernel(const P
         long long v[4];
         int lv = lane;
         asm volatile("" : "+v"(lv));                   // (per-lane addresses of the poll are formed here, not carried through the loop)
-        prk_wait_vote(a, vb, a.sums_in, r == a.r0, r, lv, (a.nblocks - (lv & (NSHARD - 1)) + NSHARD - 1) / NSHARD, failed, v);
+        prk_wait_vote(a, vb, a.sums_in, r == a.r0 ? (a.r0 == 0 ? 1 : 2) : 0, r, lv, (a.nblocks - (lv & (NSHARD - 1)) + NSHARD - 1) / NSHARD, failed, v);
         const int fl = __any(failed) ? 1 : 0;
         // the stop rule's state lives in LDS between columns (only this wave touches it): in registers it would be carried by
         // every wave of the workgroup

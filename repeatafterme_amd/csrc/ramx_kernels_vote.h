@@ -84,11 +84,12 @@ __device__ __forceinline__ void static_for(F &&f, std::integer_sequence<int, Js.
 }
 
 // Wave 0 of a workgroup, column r: the device's (multi-rank: every device's) four candidate sums of row r, identical in all
-// lanes.  `first`: the sums come as NSHARD x 4 plain int64 words (`sums0`: written by the launch before this one) instead of
-// tickets.  vb: the vote sets; my_shard_blocks: blocks arriving on shard (lane & 31).  A bounded spin that gives up sets
+// lanes.  `first` != 0: the device's sums come as NSHARD x 4 plain int64 words (`sums0`: written by the launch before this one)
+// instead of tickets; 1: they are every device's already (row 0: the host has summed them over the ranks), 2: this device's
+// only (a launch that continues a direction: the cross-device step follows as for any other row).  vb: the vote sets; my_shard_blocks: blocks arriving on shard (lane & 31).  A bounded spin that gives up sets
 // `failed`.  A: the kernel's argument block (err, nranks, rank, peers, box, mirror).
 template <class A>
-__device__ __forceinline__ void prk_wait_vote(const A &a, const PShard *vb, const long long *sums0, const bool first, const int r, const int lane,
+__device__ __forceinline__ void prk_wait_vote(const A &a, const PShard *vb, const long long *sums0, const int first, const int r, const int lane,
                                               const int my_shard_blocks, int &failed, long long (&v)[4])
 {
   v[0] = v[1] = v[2] = v[3] = 0;
@@ -143,7 +144,7 @@ __device__ __forceinline__ void prk_wait_vote(const A &a, const PShard *vb, cons
     v[0] = (r & 3) == 0; v[1] = (r & 3) == 1; v[2] = (r & 3) == 2; v[3] = (r & 3) == 3;
 #endif
   }
-  if (a.nranks > 1 && !first && !failed)
+  if (a.nranks > 1 && first != 1 && !failed)
   {
     // ---- cross-device step: v[] is this rank's total (identical in all lanes) -----------
     const unsigned long long tag = (unsigned long long)((r + PEER_TAG_OFFSET) & 0xffff) << 48;

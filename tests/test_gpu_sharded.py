@@ -78,8 +78,9 @@ def _worker(rank, world, port, out, peer=False, W=20, kind="", fail_rank=None, n
         rets.append(extend_alignment_sharded(d, c, fs.sequence, m, to_extend_params(p), rank, world, gpu_engine(dev), all_gather))
     used_persistent = dev.last.persistent
     lanes = dev.last.lanes_per_flank
+    packed = dev.last.packed_rows
     dev.close()
-    out[rank] = (rets, m.copy(), c.left_len.copy(), c.right_len.copy(), c.score.copy(), enabled, used_persistent, lanes)
+    out[rank] = (rets, m.copy(), c.left_len.copy(), c.right_len.copy(), c.score.copy(), enabled, used_persistent, lanes, packed)
     dist.destroy_process_group()
 
 
@@ -95,7 +96,7 @@ def test_two_ranks_one_gpu_equal_single_process_oracle():
     c = fs.cores.copy(); m = new_master(p.L)
     r1 = po.oracle_extend(1, c, fs.sequence, m, p); r0 = po.oracle_extend(0, c, fs.sequence, m, p)
     for rank in range(world):
-        rets, mm, ll, rl, sc, enabled, used, lanes = out[rank]
+        rets, mm, ll, rl, sc, enabled, used, lanes, packed = out[rank]
         assert rets == [(r1.ret, r1.rows_executed), (r0.ret, r0.rows_executed)], rank
         assert np.array_equal(mm, m) and np.array_equal(ll, c.left_len) and np.array_equal(rl, c.right_len)
         assert np.array_equal(sc, c.score)
@@ -122,7 +123,7 @@ def test_two_ranks_cross_device_persistent_path(W, kind, no_cp):
     c = fs.cores.copy(); m = new_master(p.L)
     r1 = po.oracle_extend(1, c, fs.sequence, m, p); r0 = po.oracle_extend(0, c, fs.sequence, m, p)
     for rank in range(world):
-        rets, mm, ll, rl, sc, enabled, used, lanes = out[rank]
+        rets, mm, ll, rl, sc, enabled, used, lanes, packed = out[rank]
         assert enabled, "peer self-test failed"
         assert used == 1, "cross-device persistent launch was not taken (or fell back)"
         assert (lanes == 1) == no_cp, lanes
@@ -147,7 +148,7 @@ def test_two_ranks_cell_parallel_long_blocks(K, monkeypatch):
     c = fs.cores.copy(); m = new_master(p.L)
     r1 = po.oracle_extend(1, c, fs.sequence, m, p); r0 = po.oracle_extend(0, c, fs.sequence, m, p)
     for rank in range(world):
-        rets, mm, ll, rl, sc, enabled, used, lanes = out[rank]
+        rets, mm, ll, rl, sc, enabled, used, lanes, packed = out[rank]
         assert enabled and used == 1 and lanes == K, (enabled, used, lanes)
         assert rets == [(r1.ret, r1.rows_executed), (r0.ret, r0.rows_executed)], rank
         assert np.array_equal(mm, m) and np.array_equal(ll, c.left_len) and np.array_equal(rl, c.right_len)
@@ -171,7 +172,7 @@ def test_two_ranks_one_launches_late(late, no_cp):
     c = fs.cores.copy(); m = new_master(p.L)
     r1 = po.oracle_extend(1, c, fs.sequence, m, p); r0 = po.oracle_extend(0, c, fs.sequence, m, p)
     for rank in range(world):
-        rets, mm, ll, rl, sc, enabled, used, lanes = out[rank]
+        rets, mm, ll, rl, sc, enabled, used, lanes, packed = out[rank]
         assert enabled and used == 1 and (lanes == 1) == no_cp
         assert rets == [(r1.ret, r1.rows_executed), (r0.ret, r0.rows_executed)], rank
         assert np.array_equal(mm, m) and np.array_equal(ll, c.left_len) and np.array_equal(rl, c.right_len)
@@ -193,7 +194,7 @@ def test_rank_local_failure_after_agreement_falls_back_on_all_ranks():
     c = fs.cores.copy(); m = new_master(p.L)
     r1 = po.oracle_extend(1, c, fs.sequence, m, p); r0 = po.oracle_extend(0, c, fs.sequence, m, p)
     for rank in range(world):
-        rets, mm, ll, rl, sc, enabled, used, lanes = out[rank]
+        rets, mm, ll, rl, sc, enabled, used, lanes, packed = out[rank]
         assert enabled
         assert used == 0, "the direction must have been repeated with per-column launches on every rank"
         assert rets == [(r1.ret, r1.rows_executed), (r0.ret, r0.rows_executed)], rank
@@ -219,9 +220,35 @@ def test_two_ranks_at_a_real_shard_size(no_cp, monkeypatch):
     c = fs.cores.copy(); m = new_master(p.L)
     r1 = po.oracle_extend(1, c, fs.sequence, m, p); r0 = po.oracle_extend(0, c, fs.sequence, m, p)
     for rank in range(world):
-        rets, mm, ll, rl, sc, enabled, used, lanes = out[rank]
+        rets, mm, ll, rl, sc, enabled, used, lanes, packed = out[rank]
         assert enabled and used == 1, (enabled, used)
         assert (lanes == 1) == no_cp, lanes
+        assert rets == [(r1.ret, r1.rows_executed), (r0.ret, r0.rows_executed)], rank
+        assert np.array_equal(mm, m) and np.array_equal(ll, c.left_len) and np.array_equal(rl, c.right_len)
+        assert np.array_equal(sc, c.score)
+
+
+@pytest.mark.parametrize("segment", ["0", "48"], ids=["one launch", "pieces of 48 columns"])
+def test_two_ranks_packed_rows_cross_device(segment, monkeypatch):
+    """The packed-row kernel on the cross-device route: each rank runs its first rows on the int32 kernel, hands the sums of the
+    next row over to the packed kernel (a launch that starts with this device's sums only: the exchange of that row follows), and
+    -- second case -- continues in pieces of 48 columns, every piece starting the same way.  2 x 20,000 flanks, results = the
+    single-process oracle; `packed_rows` shows the path was taken on every rank."""
+    from oracle import pyoracle as po
+    from repeatafterme_amd.datamodel import new_master
+    from repeatafterme_amd.synth import synth_family
+    monkeypatch.setenv("RAMX_PK_SEGMENT", segment)
+    world, shape, W = 2, (40000, 200, 150), 40
+    out = mp.Manager().dict()
+    mp.spawn(_worker, args=(world, _free_port(), out, True, W, "device", None, True, None, shape), nprocs=world, join=True)
+    fs = synth_family(shape[0], shape[1], W, K=shape[2], seed=12, both_sides=True, minus_frac=0.3, n_run_frac=0.1)
+    p = po.Params.named("14p43g", bandwidth=W, L=shape[1], when_to_stop=25)
+    c = fs.cores.copy(); m = new_master(p.L)
+    r1 = po.oracle_extend(1, c, fs.sequence, m, p); r0 = po.oracle_extend(0, c, fs.sequence, m, p)
+    for rank in range(world):
+        rets, mm, ll, rl, sc, enabled, used, lanes, packed = out[rank]
+        assert enabled and used == 1 and lanes == 1, (enabled, used, lanes)
+        assert packed > 50, packed
         assert rets == [(r1.ret, r1.rows_executed), (r0.ret, r0.rows_executed)], rank
         assert np.array_equal(mm, m) and np.array_equal(ll, c.left_len) and np.array_equal(rl, c.right_len)
         assert np.array_equal(sc, c.score)
