@@ -1631,6 +1631,7 @@ extern "C" int ramx_dev_run_direction(ramx_dev *d, ramx_run_info *info)
       // from here on a multi-rank run never leaves before the second agreement (a rank that did would leave the others'
       // kernels spinning to their limit and then waiting in a collective it never joins)
       int lrc = RAMX_OK;
+      bool accepted = false;      // the launch call went through
       auto launch = [&]() -> int
       {
         CPArgs ca;
@@ -1672,7 +1673,15 @@ extern "C" int ramx_dev_run_direction(ramx_dev *d, ramx_run_info *info)
         HIPCHK(hipEventRecord(d->ev_begin, d->stream));
         if (multi) test_delay_rank(d);
         int crc = ramx_cp_launch_device(d->stream, a.W, k, th, nb, ca);
-        if (crc != RAMX_OK) { ramx_set_error("cell-parallel device launch failed (W %d, %d lanes per flank, %d workgroups)", a.W, k, nb); return crc; }
+        if (crc != RAMX_OK)
+        {
+#ifdef RAMX_CP_TIMING
+          (void)hipFree(ca.dbg);
+#endif
+          ramx_set_error("cell-parallel device launch failed (W %d, %d lanes per flank, %d workgroups)", a.W, k, nb);
+          return crc;
+        }
+        accepted = true;          // from here on an error is the kernel's (an execution error: not something another route can serve)
         HIPCHK(hipEventRecord(d->ev_end, d->stream));
         HIPCHK(hipStreamSynchronize(d->stream));
 #ifdef RAMX_CP_TIMING
@@ -1709,10 +1718,12 @@ extern "C" int ramx_dev_run_direction(ramx_dev *d, ramx_run_info *info)
           d->peer_ready = 0;        // agreed by all ranks (the flag above is reduced)
         }
       }
+      else if (lrc != RAMX_OK && accepted)
+        return lrc;               // the kernel ran and failed (a fault is sticky: the context is gone): the error as it was reported
       else if (lrc != RAMX_OK)
       {
-        // single GPU: the other routes can serve the same flank set -- an occupancy query that says no, a launch error of
-        // this one instantiation -- so a local failure here is not the direction's failure
+        // single GPU: the other routes can serve the same flank set -- an occupancy query that says no, a launch configuration
+        // this one instantiation refuses -- so a refusal here is not the direction's failure
         (void)hipStreamSynchronize(d->stream);
         (void)hipGetLastError();
         fprintf(stderr, "ramx: cell-parallel device launch not possible (%s); continuing on the lane-per-flank route\n", ramx_last_error());

@@ -140,6 +140,19 @@ struct window
   const struct nblocks *nb;         /* N blocks of that record (shared by the windows of the record) */
 };
 
+/* first N block of a record that may reach beyond `pos` (blocks are sorted by start and do not overlap, kentsrc/twoBitNew.c:597-613:
+ * a binary search instead of a scan from block 0 for every window -- scaffold-rich assemblies have thousands per record) */
+static uint32_t first_nblock(const struct nblocks *nb, long pos)
+{
+  uint32_t lo = 0, hi = nb->count;
+  while (lo < hi)
+  {
+    const uint32_t mid = lo + (hi - lo) / 2;
+    if ((long)nb->start[mid] + (long)nb->size[mid] <= pos) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
 /* decode [start,end) of a record straight into reference base codes.  Thread-safe: reads the mapped file, a
  * 256-entry table turns one packed byte into four codes (2bit: T=0 C=1 A=2 G=3, kentsrc/dnautil.h:23-27). */
 static uint32_t g_quad[256];
@@ -181,7 +194,7 @@ static int tb_decode(const unsigned char *map, uint64_t map_len, uint64_t dna_of
     const unsigned char b = packed[(i >> 2) - p0];
     out[i - start] = (char)((g_quad[b] >> (8 * (i & 3))) & 0xff);
   }
-  for (uint32_t k = 0; k < nb->count; k++)
+  for (uint32_t k = first_nblock(nb, start); k < nb->count; k++)
   {
     long s0 = nb->start[k], e0 = s0 + nb->size[k];
     if (s0 >= end) break;
@@ -373,7 +386,7 @@ static double ld_now(void)
 }
 #define LD_PHASE(name) do { if (timing) { const double t_ = ld_now(); fprintf(stderr, "RAMX_TIMING   loader: %-14s %9.3f ms\n", name, t_ - t_last); t_last = t_; } } while (0)
 
-/* ---- record headers, read by worker threads (pread: no shared file position) ---------------------------------------- */
+/* ---- record headers, read by worker threads from the mapped file -------------------------------------------------------- */
 struct rec_hdr
 {
   uint64_t offset;                  /* of the record in the file (from the index) */
@@ -404,8 +417,11 @@ static void *hdr_worker(void *arg)
     r->size = j->swapped ? bswap32(h[0]) : h[0];
     r->nb.count = j->swapped ? bswap32(h[1]) : h[1];
     const size_t nbn = r->nb.count;
+    /* a count the file cannot hold (corrupt or truncated header) is refused before anything is allocated for it */
+    if (r->offset + 8 > j->map_len || (uint64_t)8 * nbn > j->map_len - (r->offset + 8)) { r->nb.count = 0; r->failed = 1; continue; }
     r->nb.start = (uint32_t *)malloc(sizeof(uint32_t) * (nbn ? nbn : 1));
     r->nb.size = (uint32_t *)malloc(sizeof(uint32_t) * (nbn ? nbn : 1));
+    if (r->nb.start == NULL || r->nb.size == NULL) { r->nb.count = 0; r->failed = 2; continue; }
     if (nbn && (map_read(j->map, j->map_len, r->nb.start, 4 * nbn, r->offset + 8) != 0 ||
                 map_read(j->map, j->map_len, r->nb.size, 4 * nbn, r->offset + 8 + 4 * nbn) != 0)) { r->failed = 1; continue; }
     if (j->swapped) for (size_t k = 0; k < nbn; k++) { r->nb.start[k] = bswap32(r->nb.start[k]); r->nb.size[k] = bswap32(r->nb.size[k]); }
@@ -538,7 +554,11 @@ static struct sequenceLibrary *load_subset(const char *twoBitName, const char *r
     hdr_worker(&jobs[0]);
     for (int t = 1; t < nthreads; t++) if (tid[t]) pthread_join(tid[t], NULL);
     free(jobs); free(tid);
-    for (int k = 0; k < nrec; k++) if (rec[k].failed) die255("%s is truncated", tb->path, 0, 0);
+    for (int k = 0; k < nrec; k++)
+    {
+      if (rec[k].failed == 2) die255("out of memory reading the N blocks of %s", tb->path, 0, 0);
+      if (rec[k].failed) die255("%s is truncated", tb->path, 0, 0);
+    }
   }
   LD_PHASE("record headers");
 
@@ -561,12 +581,13 @@ static struct sequenceLibrary *load_subset(const char *twoBitName, const char *r
       die255("twoBitReadSeqFrag in %s start (%ld) >= end (%ld)", s->name, win[i].flank_start, win[i].flank_end);
     total += (uint64_t)(win[i].flank_end - win[i].flank_start);
     total_bytes += (uint64_t)(((win[i].flank_end + 3) >> 2) - (win[i].flank_start >> 2));
-    for (uint32_t k = 0; k < r->nb.count; k++)      /* N runs that touch the window (twoBitNew.c:597-613) */
-    {
-      const long s0 = r->nb.start[k], e0 = s0 + r->nb.size[k];
-      if (s0 >= win[i].flank_end) break;
-      if (e0 > win[i].flank_start) n_runs++;
-    }
+    if (mode & 2)                                    /* N runs that touch the window (twoBitNew.c:597-613); only the packed twin keeps them */
+      for (uint32_t k = first_nblock(&r->nb, win[i].flank_start); k < r->nb.count; k++)
+      {
+        const long s0 = r->nb.start[k], e0 = s0 + r->nb.size[k];
+        if (s0 >= win[i].flank_end) break;
+        if (e0 > win[i].flank_start) n_runs++;
+      }
   }
   at_of[n] = total;
   byte_of[n] = total_bytes;
@@ -592,7 +613,7 @@ static struct sequenceLibrary *load_subset(const char *twoBitName, const char *r
     {
       phase[i] = (uint8_t)(win[i].flank_start & 3);
       const struct nblocks *nb = win[i].nb;
-      for (uint32_t k = 0; k < nb->count; k++)      /* clipped to the window, in library coordinates (sorted: windows are) */
+      for (uint32_t k = first_nblock(nb, win[i].flank_start); k < nb->count; k++)      /* clipped to the window, in library coordinates (sorted: windows are) */
       {
         long s0 = nb->start[k], e0 = s0 + nb->size[k];
         if (s0 >= win[i].flank_end) break;
@@ -604,7 +625,7 @@ static struct sequenceLibrary *load_subset(const char *twoBitName, const char *r
     pl->length = total; pl->n_windows = n; pl->win_start = at_of; pl->win_byte = byte_of; pl->win_phase = phase;
     pl->bytes = packed; pl->n_bytes = total_bytes; pl->n_start = ns; pl->n_len = nl; pl->n_blocks = (int32_t)q;
   }
-  /* every window: independent reads (pread) and writes, split over the host cores by bases */
+  /* every window: independent reads of the mapped file and writes, split over the host cores by bases */
   {
     quad_init();
     int nthreads = loader_threads(total, 8u << 20);

@@ -142,6 +142,40 @@ def test_loader_error_paths(tmp_path):
     assert r.returncode == 255 and "valid twoBitSig" in r.stderr
     r = subprocess.run(["python3", "-c", code, tb, ok], capture_output=True, text=True)
     assert r.returncode == 0
+    # a record header whose N-block count the file cannot hold (corrupt / truncated): an error message, not a crash
+    raw = bytearray(open(tb, "rb").read())
+    off = struct.unpack("<I", raw[16 + 1 + 1:16 + 1 + 1 + 4])[0]          # index entry: length byte, "s", offset
+    raw[off + 4:off + 8] = struct.pack("<I", 0x7fffffff)
+    corrupt = str(tmp_path / "c.2bit"); open(corrupt, "wb").write(bytes(raw))
+    r = subprocess.run(["python3", "-c", code, corrupt, ok], capture_output=True, text=True)
+    assert r.returncode == 255 and "truncated" in r.stderr, (r.returncode, r.stderr)
+    cut = str(tmp_path / "cut.2bit"); open(cut, "wb").write(open(tb, "rb").read()[:off + 6])
+    r = subprocess.run(["python3", "-c", code, cut, ok], capture_output=True, text=True)
+    assert r.returncode == 255 and "truncated" in r.stderr, (r.returncode, r.stderr)
+
+
+def test_many_n_blocks_per_record(tmp_path):
+    """A record with hundreds of N blocks and windows all along it: the blocks that touch a window are found by a binary search
+    (csrc/ramx_loader.c first_nblock), byte loader and packed loader agree with the plain array."""
+    rng = np.random.default_rng(11)
+    a = rng.integers(0, 4, 40000).astype(np.int8)
+    starts = np.sort(rng.choice(np.arange(10, 39900, 50), 400, replace=False))
+    for st in starts:
+        a[st:st + int(rng.integers(1, 30))] = 99
+    tb = str(tmp_path / "n.2bit"); write_twobit(tb, [("rec", a)])
+    ranges = [("rec", int(x), int(x) + 20, 1, 1, "+" if i % 2 else "-") for i, x in enumerate(range(100, 39000, 700))]
+    bed = str(tmp_path / "n.tsv"); write_ranges(bed, ranges)
+    fs = load_sequence_subset_minimal(tb, bed, 150)
+    fp, t = load_sequence_subset_packed(tb, bed, 150)
+    assert np.array_equal(fs.sequence, fp.sequence) and fs.cores.n == len(ranges)
+    isn = np.zeros(len(fs.sequence), bool)
+    for s0, ln in zip(t["n_start"], t["n_len"]):
+        isn[int(s0):int(s0) + int(ln)] = True
+    assert np.array_equal(isn, fs.sequence == 99) and isn.sum() > 100
+    for i in range(fs.cores.n):
+        lo = 0 if i == 0 else int(fs.boundaries[i - 1])
+        hi = int(fs.boundaries[i]); o = int(fs.offsets[i])
+        assert np.array_equal(fs.sequence[lo:hi], a[o:o + hi - lo]), i
 
 
 def test_overlap_avoidance_vs_quadratic_restatement():
