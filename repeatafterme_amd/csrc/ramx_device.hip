@@ -748,6 +748,7 @@ static int d2h_small(ramx_dev *d, void *dst, const void *src, size_t bytes)
   return RAMX_OK;
 }
 
+#define RAMX_CP_MIN_K_OVER_PACKED 4      // the cell-parallel kernel goes first with at least this many lanes per flank
 static int prk_local_can(ramx_dev *d, const KArgs &a, int L, bool multi, bool *can_out, int *block, int *blocks)
 {
   const int W = a.W;
@@ -899,6 +900,13 @@ static int prk_run(ramx_dev *d, const KArgs &a, int L, bool *used)
     ka.S = d->d_state[0]; ka.bases = d->d_bases; ka.bounds = d->d_bounds; ka.trim = d->d_trim;
     ka.vote = d->d_vote; ka.cons_out = d->d_cons; ka.err = d->d_err;
     ka.peers = pa.peers; ka.box = pa.box; ka.mirror = pa.mirror; ka.rank = pa.rank; ka.nranks = pa.nranks;
+    ka.xblock = 0;
+    if (ka.nranks > 1 && getenv("RAMX_NO_PK_EXCHANGER") == NULL)
+    {
+      // a CU to spare: the device's exchange duties get a workgroup of their own (ramx_kernels_packed.h)
+      int cap = 0;
+      if (ramx_pk_capacity(W, pk_block, &cap) == RAMX_OK && pk_blocks + 1 <= cap) ka.xblock = pk_blocks;
+    }
     ka.Np = d->Np; ka.Nx = d->Nx; ka.L = L; ka.go = a.go; ka.ge = a.ge; ka.cap = a.cap; ka.minimp = a.minimp;
     ka.when_to_stop = a.when_to_stop; ka.nblocks = pk_blocks;
     memcpy(ka.tab, a.tab, sizeof(ka.tab));
@@ -1589,6 +1597,7 @@ extern "C" int ramx_dev_run_direction(ramx_dev *d, ramx_run_info *info)
         HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
         const char *mx = getenv("RAMX_CP_DEVICE_MAXN");
         if (mx == NULL || d->Nx <= atoi(mx)) ramx_cp_device_plan(a.W, d->Nx, cus, 0, &k, &th, &nb, &vwf);
+        if (k > 0 && k < RAMX_CP_MIN_K_OVER_PACKED && getenv("RAMX_CP_K") == NULL) k = 0;      // (the packed-row kernel is the faster one there, see below)
         if (k > 0) lazy = false;
       }
     }
@@ -1605,6 +1614,18 @@ extern "C" int ramx_dev_run_direction(ramx_dev *d, ramx_run_info *info)
     const char *mx = getenv("RAMX_CP_DEVICE_MAXN");
     if (d->cp_flanks_ok && ramx_cp_max_family(a.W, a.go, a.ge, d->tab, L) > 0 && (mx == NULL || d->Nx <= atoi(mx)))
       ramx_cp_device_plan(a.W, d->Nx > 0 ? d->Nx : 1, cus, 0, &k, &th, &nb, &vwf);
+    if (k > 0 && k < RAMX_CP_MIN_K_OVER_PACKED && getenv("RAMX_CP_K") == NULL)
+    {
+      // Two lanes per flank (33,000-65,536 flanks at W = 40) against the packed-row kernel with one wave per SIMD, whole bench launch
+      // at 50,000 / 65,000 flanks: 5.44 / 5.55 against 4.76 / 4.66 us per column (aligned phase alike, the capped tail is the packed
+      // kernel's; profiles/r04_route_ab.log) -- where the packed rows can run they take those sets.
+      int blk = 0, blks = 0, sp = 0, rb = 0, pb = 0, pbs = 0;
+      bool can32 = false, pkq = false;
+      int lrc = prk_local_can(d, a, L, multi, &can32, &blk, &blks);
+      if (lrc != RAMX_OK) return lrc;
+      if ((lrc = pk_route(d, a, L, multi, can32, &pkq, &sp, &rb, &pb, &pbs)) != RAMX_OK) return lrc;
+      if (pkq) k = 0;
+    }
     if (multi)
     {
       // my mailbox is cleared BEFORE the agreement, which no remote launch can get past without my taking part

@@ -290,6 +290,35 @@ __device__ __forceinline__ void pkb_leader_rows(const PkTabs &pt, int *scr /* [2
   }
 }
 
+// The vote wave's part of a column (ram_extend.c:1064-1086, 1194-1223), shared by the workgroups' vote waves and the exchanger:
+// the four sums of row r -> winner, new maximum, stop; the stop rule's state lives in `st` (LDS: max_ext in two words, max_row,
+// overflow).  Wave-uniform: runs on the scalar unit.  Returns winner | new maximum << 2 | stop << 3 | failure << 4.
+template <class A>
+__device__ __forceinline__ int pkb_stop_rule(const A &a, const int r, const long long (&v)[4], const int fl, int *st, const int lane)
+{
+  long long mx = ((long long)__builtin_amdgcn_readfirstlane(st[1]) << 32) | (long long)(unsigned)__builtin_amdgcn_readfirstlane(st[0]);
+  int mr = __builtin_amdgcn_readfirstlane(st[2]), ov = __builtin_amdgcn_readfirstlane(st[3]);
+  long long cw = 0;
+  int bw = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+  {
+    const long long vk = ((long long)__builtin_amdgcn_readfirstlane((int)(v[k] >> 32)) << 32) |
+                         (long long)(unsigned)__builtin_amdgcn_readfirstlane((int)v[k]);
+    if (vk > 2147483647LL || vk < -2147483648LL) ov = 1;
+    if (vk > cw) { cw = vk; bw = k; }
+  }
+  int dist = mr - r;
+  dist = dist < 0 ? -dist : dist;
+  const int nm = cw >= mx + (long long)dist * a.minimp ? 1 : 0;
+  if (nm && !fl) { mr = r; mx = cw; }
+  int d2 = r - mr;
+  d2 = d2 < 0 ? -d2 : d2;
+  const int stp = d2 >= a.when_to_stop ? 1 : 0;
+  if (lane == 0) { st[0] = (int)mx; st[1] = (int)(mx >> 32); st[2] = mr; st[3] = ov; }
+  return bw | (nm << 2) | (stp << 3) | (fl << 4);
+}
+
 #ifdef RAMX_PRK_TIMING
 // (-DRAMX_PRK_TIMING_TAIL: only the second half of the columns is accounted)
 #ifdef RAMX_PRK_TIMING_TAIL
@@ -364,6 +393,36 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 256) void ramx_packed_kernel(const P
   rows_done = __builtin_amdgcn_readfirstlane(rows_done); carried = __builtin_amdgcn_readfirstlane(carried);
   const bool skip = stopped || failed || a.r0 >= a.Lseg;
   if (threadIdx.x == 0) { sm.st[0] = (int)max_ext; sm.st[1] = (int)(max_ext >> 32); sm.st[2] = max_row; sm.st[3] = ovf; }
+
+  // ---- the exchanger (multi-rank runs, when the device has a CU to spare): a workgroup WITHOUT flanks behind the last one.
+  // Its first wave does what is the device's business rather than a workgroup's -- it waits for the local total of every row,
+  // stores it into every rank's box, writes the consensus and clears the vote set three rows ahead -- and nothing else, so
+  // the local total crosses the fabric as soon as the last ticket is in.  In workgroup 0 the same duties wait for that
+  // workgroup's own row: with rows computed ahead of the vote, everybody's vote then arrives a whole band late
+  // (two ranks on one GPU: 8.3 against 5.8 us per column for one rank, profiles/r04_two_rank.log).
+  if (blockIdx.x == a.nblocks)
+  {
+    if (wave != 0 || stopped || failed || a.r0 >= a.Lseg) return;
+    for (int r = a.r0; r < a.Lseg; r++)
+    {
+      PShard *vb = a.vote;
+      asm volatile("" : "+s"(vb));
+      long long v[4];
+      prk_wait_vote(a, vb, a.sums_in, r == a.r0 ? (a.r0 == 0 ? 1 : 2) : 0, r, lane, (a.nblocks - (lane & (NSHARD - 1)) + NSHARD - 1) / NSHARD, failed, v, true);
+      const int fl = __any(failed) ? 1 : 0;
+      const int dword = pkb_stop_rule(a, r, v, fl, sm.st, lane);
+      if (fl) { if (lane == 0) __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      if (lane == 0) a.cons_out[r] = (signed char)(dword & 3);
+      if (lane < NSHARD)
+      {
+        PShard *z = vb + (size_t)((r + 3) & (PRK_NSETS - 1)) * NSHARD + lane;
+#pragma unroll
+        for (int k = 0; k < 4; k++) __hip_atomic_store(&z->word[k], 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if ((dword & 8) || r == a.L - 1) break;
+    }
+    return;
+  }
 
   // ---- row state -> packed registers -----------------------------------------------------------
   int R[NP], E[NP];
@@ -500,37 +559,18 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 256) void ramx_packed_kernel(const P
         long long v[4];
         int lv = lane;
         asm volatile("" : "+v"(lv));                   // (per-lane addresses of the poll are formed here, not carried through the loop)
-        prk_wait_vote(a, vb, a.sums_in, r == a.r0 ? (a.r0 == 0 ? 1 : 2) : 0, r, lv, (a.nblocks - (lv & (NSHARD - 1)) + NSHARD - 1) / NSHARD, failed, v);
+        prk_wait_vote(a, vb, a.sums_in, r == a.r0 ? (a.r0 == 0 ? 1 : 2) : 0, r, lv, (a.nblocks - (lv & (NSHARD - 1)) + NSHARD - 1) / NSHARD, failed, v, blockIdx.x == a.xblock);
         const int fl = __any(failed) ? 1 : 0;
         // the stop rule's state lives in LDS between columns (only this wave touches it): in registers it would be carried by
         // every wave of the workgroup
-        long long mx = ((long long)__builtin_amdgcn_readfirstlane(sm.st[1]) << 32) | (long long)(unsigned)__builtin_amdgcn_readfirstlane(sm.st[0]);
-        int mr = __builtin_amdgcn_readfirstlane(sm.st[2]), ov = __builtin_amdgcn_readfirstlane(sm.st[3]);
-        long long cw = 0;
-        int bw = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-        {
-          // the vote is wave-uniform: the whole stop rule runs on the scalar unit (ram_extend.c:1064-1086, 1194-1223)
-          const long long vk = ((long long)__builtin_amdgcn_readfirstlane((int)(v[k] >> 32)) << 32) |
-                               (long long)(unsigned)__builtin_amdgcn_readfirstlane((int)v[k]);
-          if (vk > 2147483647LL || vk < -2147483648LL) ov = 1;
-          if (vk > cw) { cw = vk; bw = k; }
-        }
-        int dist = mr - r;
-        dist = dist < 0 ? -dist : dist;
-        const int nm = cw >= mx + (long long)dist * a.minimp ? 1 : 0;
-        if (nm && !fl) { mr = r; mx = cw; }
-        int d2 = r - mr;
-        d2 = d2 < 0 ? -d2 : d2;
-        const int st = d2 >= a.when_to_stop ? 1 : 0;
+        const int dword = pkb_stop_rule(a, r, v, fl, sm.st, lane);
+        const int bw = dword & 3;
         if (lane == 0)
         {
-          sm.st[0] = (int)mx; sm.st[1] = (int)(mx >> 32); sm.st[2] = mr; sm.st[3] = ov;
-          sm.word[par][0] = bw | (nm << 2) | (st << 3) | (fl << 4);
+          sm.word[par][0] = dword;
           if (fl) __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (blockIdx.x == 0 && !fl)
+        if (blockIdx.x == a.xblock && !fl)
         {
           if (lane == 0) a.cons_out[r] = (signed char)bw;
           // block 0 clears the vote set of row r+3 (ramx_kernels_vote.h)

@@ -532,7 +532,7 @@ __global__ __launch_bounds__(BLOCK, (W > 40 ? 1 : 2)) void ramx_persistent_kerne
     if (wave == 0)
     {
       long long v[4];
-      prk_wait_vote(a, a.vote, a.sums0, r == 0 ? 1 : 0, r, lane, my_shard_blocks, failed, v);
+      prk_wait_vote(a, a.vote, a.sums0, r == 0 ? 1 : 0, r, lane, my_shard_blocks, failed, v, blockIdx.x == 0);
       {
         // the winner's substitution column of the fast-path tables (same argmax rule as below, ram_extend.c:1064-1086)
         long long cw = 0;

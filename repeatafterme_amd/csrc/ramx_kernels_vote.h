@@ -87,10 +87,12 @@ __device__ __forceinline__ void static_for(F &&f, std::integer_sequence<int, Js.
 // lanes.  `first` != 0: the device's sums come as NSHARD x 4 plain int64 words (`sums0`: written by the launch before this one)
 // instead of tickets; 1: they are every device's already (row 0: the host has summed them over the ranks), 2: this device's
 // only (a launch that continues a direction: the cross-device step follows as for any other row).  vb: the vote sets; my_shard_blocks: blocks arriving on shard (lane & 31).  A bounded spin that gives up sets
-// `failed`.  A: the kernel's argument block (err, nranks, rank, peers, box, mirror).
+// `failed`.  A: the kernel's argument block (err, nranks, rank, peers, box, mirror).  xb: this workgroup is the device's
+// EXCHANGER (multi-rank: the one that waits for the local total and stores it into every rank's box; workgroup 0, or a
+// workgroup without flanks launched for the purpose, ramx_kernels_packed.h).
 template <class A>
 __device__ __forceinline__ void prk_wait_vote(const A &a, const PShard *vb, const long long *sums0, const int first, const int r, const int lane,
-                                              const int my_shard_blocks, int &failed, long long (&v)[4])
+                                              const int my_shard_blocks, int &failed, long long (&v)[4], const bool xb)
 {
   v[0] = v[1] = v[2] = v[3] = 0;
   if (first)
@@ -106,7 +108,7 @@ __device__ __forceinline__ void prk_wait_vote(const A &a, const PShard *vb, cons
     const int sidx = lane & (NSHARD - 1), half = lane >> 5;
     const unsigned long long *src = &vb[(size_t)(r & (PRK_NSETS - 1)) * NSHARD + sidx].word[2 * half];
     unsigned spins = 0;
-    bool done = my_shard_blocks <= 0 || (a.nranks > 1 && blockIdx.x != 0);   // multi-rank: only the exchanger needs the local total
+    bool done = my_shard_blocks <= 0 || (a.nranks > 1 && !xb);   // multi-rank: only the exchanger needs the local total
 #ifdef PRK_PROBE_NO_WAIT
     done = true;         // timing probe (wrong results by construction): nobody waits for the vote, the winner rotates
 #endif
@@ -132,7 +134,7 @@ __device__ __forceinline__ void prk_wait_vote(const A &a, const PShard *vb, cons
     }
     // fold the 32 shards: the raw words first (sum + bias and ticket fields are both additive: at most 256 tickets,
     // ten bits), rows of 16 lanes with DPP butterflies, the four rows on the scalar unit; one decode per word
-    if (my_shard_blocks <= 0 || failed || (a.nranks > 1 && blockIdx.x != 0)) { x0 = 0; x1 = 0; }
+    if (my_shard_blocks <= 0 || failed || (a.nranks > 1 && !xb)) { x0 = 0; x1 = 0; }
     x0 = prk_row_sum_u64(x0); x1 = prk_row_sum_u64(x1);
     const unsigned long long t0 = prk_readlane_u64(x0, 0) + prk_readlane_u64(x0, 16), t1 = prk_readlane_u64(x1, 0) + prk_readlane_u64(x1, 16);
     const unsigned long long t2 = prk_readlane_u64(x0, 32) + prk_readlane_u64(x0, 48), t3 = prk_readlane_u64(x1, 32) + prk_readlane_u64(x1, 48);
@@ -148,7 +150,7 @@ __device__ __forceinline__ void prk_wait_vote(const A &a, const PShard *vb, cons
   {
     // ---- cross-device step: v[] is this rank's total (identical in all lanes) -----------
     const unsigned long long tag = (unsigned long long)((r + PEER_TAG_OFFSET) & 0xffff) << 48;
-    if (blockIdx.x == 0 && lane < a.nranks)
+    if (xb && lane < a.nranks)
     {
       PeerBox *pb = a.peers[lane];
 #pragma unroll
@@ -162,7 +164,7 @@ __device__ __forceinline__ void prk_wait_vote(const A &a, const PShard *vb, cons
     unsigned long long y[4] = { 0, 0, 0, 0 };
     bool got = lane >= a.nranks;
     unsigned spins = 0;
-    const PeerBox *pollbox = (a.mirror != NULL && blockIdx.x != 0) ? a.mirror : a.box;
+    const PeerBox *pollbox = (a.mirror != NULL && !xb) ? a.mirror : a.box;
     for (;;)
     {
       if (!got)
@@ -170,7 +172,7 @@ __device__ __forceinline__ void prk_wait_vote(const A &a, const PShard *vb, cons
 #pragma unroll
         for (int k = 0; k < 4; k++) y[k] = __hip_atomic_load(&pollbox->slot[r % 3][lane][k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         got = (y[0] >> 48) == (tag >> 48) && (y[1] >> 48) == (tag >> 48) && (y[2] >> 48) == (tag >> 48) && (y[3] >> 48) == (tag >> 48);
-        if (got && a.mirror != NULL && blockIdx.x == 0)
+        if (got && a.mirror != NULL && xb)
         {
           // this rank's word of this column has arrived: pass it on to the local pollers
 #pragma unroll

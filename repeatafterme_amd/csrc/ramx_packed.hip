@@ -67,6 +67,17 @@ static int pk_shape(int tiles, int *block, int *blocks)
   return RAMX_OK;
 }
 
+// workgroups of `block` threads the device holds at once (what ramx_pk_shape compared `blocks` with)
+int ramx_pk_capacity(int W, int block, int *cap)
+{
+  *cap = 0;
+  if (block == 256)
+    switch (W) { case 14: return pk_capacity<14, 256>(cap); case 20: return pk_capacity<20, 256>(cap); case 40: return pk_capacity<40, 256>(cap); case 80: return pk_capacity<80, 256>(cap); }
+  if (block == 512)
+    switch (W) { case 14: return pk_capacity<14, 512>(cap); case 20: return pk_capacity<20, 512>(cap); case 40: return pk_capacity<40, 512>(cap); }
+  return RAMX_OK;
+}
+
 int ramx_pk_shape(int W, int tiles, int *block, int *blocks)
 {
   switch (W)
@@ -83,10 +94,11 @@ int ramx_pk_shape(int W, int tiles, int *block, int *blocks)
 template <int W>
 static int pk_launch(hipStream_t st, int block, int blocks, const PKArgs &a)
 {
-  if (block == 256) hipLaunchKernelGGL((ramx_packed_kernel<W, 256>), dim3(blocks), dim3(256), 0, st, a);
+  const int grid = blocks + (a.xblock != 0 ? 1 : 0);       // + the exchanger (ramx_kernels_packed.h)
+  if (block == 256) hipLaunchKernelGGL((ramx_packed_kernel<W, 256>), dim3(grid), dim3(256), 0, st, a);
   else if (block == 512)
   {
-    if constexpr (W <= 40) hipLaunchKernelGGL((ramx_packed_kernel<W, 512>), dim3(blocks), dim3(512), 0, st, a);
+    if constexpr (W <= 40) hipLaunchKernelGGL((ramx_packed_kernel<W, 512>), dim3(grid), dim3(512), 0, st, a);
     else return RAMX_ERR_ARG;
   }
   else return RAMX_ERR_ARG;

@@ -25,6 +25,7 @@ struct PKArgs
   PeerBox *box;
   PeerBox *mirror;
   int rank, nranks;
+  int xblock;                   // the workgroup that does the device's exchange duties: 0, or nblocks (one more workgroup, without flanks)
   long long *sums_next;         // Lseg < L: the sums of row Lseg as NSHARD x 4 plain int64 words (zeroed by the host) for the launch that continues
   int Np, Nx, r0, Lseg, L, go, ge, cap, minimp, when_to_stop, nblocks;      // this launch runs rows r0 .. Lseg-1 of a direction of L rows
   int tab[RAMX_NCLASS][4];
@@ -41,5 +42,6 @@ struct PKArgs
 // 0: no (the int32 rows serve it).
 int ramx_pk_plan(int W, int go, int ge, const int (&tab)[RAMX_NCLASS][4], int *spread, int *rebase);
 // launch shape that keeps `tiles` 64-flank tiles resident (at most one workgroup per CU): block = 0 if none
+int ramx_pk_capacity(int W, int block, int *cap);
 int ramx_pk_shape(int W, int tiles, int *block, int *blocks);
 int ramx_pk_launch(hipStream_t st, int W, int block, int blocks, const PKArgs &a);
