@@ -149,6 +149,8 @@ def main():
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
                     help="N > 1: strong = the --flanks set is split over the ranks (BASELINE configs[3]); weak = --flanks per rank")
     ap.add_argument("--no-seam1", action="store_true", help="skip the seam-1 (ramx_extend_flat, host buffers) timing")
+    ap.add_argument("--no-phases", action="store_true", help="skip the extra launch that separates aligned phase and capped tail "
+                    "(profiling runs: every dispatch of the kernel is then a timed step)")
     ap.add_argument("--L", type=int, default=10000)
     ap.add_argument("--bandwidth", type=int, default=40)
     ap.add_argument("--cpu-flanks", type=int, default=20000)
@@ -394,7 +396,7 @@ def main():
     # columns behind the end of the alignment) and the CAPPED TAIL (flanks at their caps: LEAN rows, exact and digest-checked, but
     # cheaper).  One more launch over the first K columns separates them.
     phases = None
-    if world == 1 and persistent and lanes == 1 and L > 1500 and args.ragged == 0:
+    if world == 1 and persistent and lanes == 1 and L > 1500 and args.ragged == 0 and not args.no_phases:
         K = 1500
         pk = ExtendParams(bandwidth=W, cappenalty=p.cappenalty, minimprovement=p.minimprovement, L=K, when_to_stop=K, l=1,
                           gapopen=go, gapextn=ge, matrix=mat, matrix_name="14p43g")

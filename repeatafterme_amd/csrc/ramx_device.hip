@@ -334,10 +334,12 @@ static int pack_rest(ramx_dev *d)
   d->packed_kw = d->KW;
   return rc;
 }
-static int pk_segment_columns(void)
+static int pk_segment_columns(int L, int when_to_stop)
 {
   const char *e = getenv("RAMX_PK_SEGMENT");
-  const int v = e ? atoi(e) : 2048;
+  // a direction whose stop rule cannot fire before its last column (-stopafter >= L: every column is wanted) reads its whole
+  // window anyway: one piece
+  const int v = e ? atoi(e) : (when_to_stop >= L ? 0 : 2048);
   return v < 0 ? 0 : v;          // 0: the whole direction in one piece (everything packed at once)
 }
 
@@ -394,7 +396,7 @@ extern "C" int ramx_dev_begin_direction(ramx_dev *d, const ramx_flank *flanks, i
   if (Nx) HIPCHK(hipMemcpyAsync(d->d_flanks, flanks, (size_t)Nx * sizeof(ramx_flank), hipMemcpyHostToDevice, d->stream));
   {
     if (d->pack_busy) { HIPCHK(hipStreamWaitEvent(d->stream, d->pack_done, 0)); d->pack_busy = 0; }    // (a piece of the direction before still in flight)
-    const int seg = pk_segment_columns();
+    const int seg = pk_segment_columns(p->L, p->when_to_stop);
     const int first = seg > 0 ? ((seg + 8) >> 3) + 28 : KW;      // words the first piece's columns read (+ the widest band's window and look-ahead)
     d->packed_kw = first < KW ? first : KW;
     if ((rc = launch_pack(d, Nx, Np, W, 0, d->packed_kw, d->stream)) != RAMX_OK) return rc;
@@ -917,7 +919,7 @@ static int prk_run(ramx_dev *d, const KArgs &a, int L, bool *used)
     // The direction runs in pieces of RAMX_PK_SEGMENT columns (one launch each: rows written back, sums of the next row handed
     // over as plain words, control block passed on), so that only the base words a run really reads are ever packed: the
     // next piece's words are packed on a second stream while this piece runs.
-    const int seg = pk_segment_columns();
+    const int seg = pk_segment_columns(L, a.when_to_stop);
     const int NWw = (2 * W + 1 + 8) / 8 + 2;
     long long *sbuf[2] = { d->d_sums + (size_t)NSHARD * 4, d->d_sums + (size_t)2 * NSHARD * 4 };     // slots 1 and 2
     const long long *sums_in = pk_r0 > 0 ? sbuf[0] : d->d_sums;

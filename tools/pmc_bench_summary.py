@@ -9,9 +9,10 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, cols, flanks, W = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
 doc = json.load(open(os.path.join(root, "profiles", f"{tag}_pmc_bench.json")))
 ent = None
-for k, v in doc.items():
-    if "ramx_persistent_kernel" in k:
-        ent = v
+for want in ("ramx_packed_kernel", "ramx_persistent_kernel"):      # the packed rows are the bench's kernel since round 4
+    for k, v in doc.items():
+        if want in k and ent is None:
+            ent = v
 assert ent is not None, list(doc)
 a = ent["avg_per_dispatch"]
 out = {"tag": tag, "persistent": {"dispatches": ent["dispatches"], "avg_per_dispatch": a, "columns_per_launch": cols}}
@@ -22,6 +23,9 @@ if "FETCH_SIZE" in a and "WRITE_SIZE" in a:
     p["write_bytes"] = a["WRITE_SIZE"] * 1024
     p["hbm_bytes_per_launch"] = p["fetch_bytes_corrected"] + p["write_bytes"]
     p["hbm_bytes_per_column"] = p["hbm_bytes_per_launch"] / cols
+sys.path.insert(0, root)
+from bench import device_source_sha16
+out["device_source_sha16"] = device_source_sha16()      # bench.py uses these counters only for the sources they were collected on
 out["config"] = {"flanks": flanks, "bandwidth": W, "L": cols,
                  "command": "python3 bench.py --steps 1 --warmup 0 --no-cpu --no-seam1   (one rocprofv3 --pmc pass per counter set)"}
 dst = os.path.join(root, "profiles", "pmc_summary.json")
