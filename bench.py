@@ -352,7 +352,7 @@ def main():
         ginst = insts_per_col / (us_col * 1e-6) / 1e9           # wave64 VALU instructions per second, whole chip
         mix = None
         try:
-            mix = json.load(open(os.path.join(ROOT, "profiles", "r03_valu_mix_persistent.json")))
+            mix = json.load(open(os.path.join(ROOT, "profiles", "r04_valu_mix_packed.json")))
         except Exception:
             pass
         valu = {"insts_per_column": insts_per_col, "G_wave_inst_per_sec": ginst, "pmc_source": pmc_source,

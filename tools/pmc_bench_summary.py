@@ -29,7 +29,16 @@ out["device_source_sha16"] = device_source_sha16()      # bench.py uses these co
 out["config"] = {"flanks": flanks, "bandwidth": W, "L": cols,
                  "command": "python3 bench.py --steps 1 --warmup 0 --no-cpu --no-seam1   (one rocprofv3 --pmc pass per counter set)"}
 dst = os.path.join(root, "profiles", "pmc_summary.json")
-if os.path.exists(dst):   # the 256-column full-band count is measured separately (tools/pmc.sh); keep it across refreshes
+# what a column costs when every row is FULL: the same counters over the aligned phase alone (a launch over the first 1,500
+# columns of the bench set, profiles/TAG_pmc_aligned.json)
+al = os.path.join(root, "profiles", f"{tag}_pmc_aligned.json")
+if os.path.exists(al):
+    acols = int(sys.argv[5]) if len(sys.argv) > 5 else 1500
+    for k, v in json.load(open(al)).items():
+        if "ramx_packed_kernel" in k and "SQ_INSTS_VALU" in v["avg_per_dispatch"]:
+            out["persistent"]["full_band_insts_per_column"] = v["avg_per_dispatch"]["SQ_INSTS_VALU"] / acols
+            out["persistent"]["full_band_source"] = f"profiles/{tag}_pmc_aligned.json (SQ_INSTS_VALU of a {acols}-column launch over the aligned phase of the bench set: every row FULL)"
+elif os.path.exists(dst):
     old = json.load(open(dst)).get("persistent", {})
     for k in ("full_band_insts_per_column", "full_band_source"):
         if k in old:
