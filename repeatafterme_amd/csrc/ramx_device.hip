@@ -1584,7 +1584,7 @@ extern "C" int ramx_dev_run_direction(ramx_dev *d, ramx_run_info *info)
   rt_mark(NULL);
   {
     bool lazy = false;
-    if (!tracing && !multi && d->Nx > 0)
+    if (!tracing && d->Nx > 0)
     {
       int blk = 0, blks = 0, sp = 0, rb = 0, pb = 0, pbs = 0;
       bool can32 = false;
@@ -1592,7 +1592,8 @@ extern "C" int ramx_dev_run_direction(ramx_dev *d, ramx_run_info *info)
       if (lrc != RAMX_OK) return lrc;
       if ((lrc = pk_route(d, a, L, multi, can32, &lazy, &sp, &rb, &pb, &pbs)) != RAMX_OK) return lrc;
       // (the device-wide cell-parallel kernel goes first where it applies: it takes the whole window)
-      if (lazy && d->cp_flanks_ok && getenv("RAMX_NO_CP_DEVICE") == NULL && ramx_cp_max_family(a.W, a.go, a.ge, d->tab, L) > 0)
+      // (multi-rank: the route is agreed below; whichever kernel then needs the whole window packs the rest first)
+      if (lazy && !multi && d->cp_flanks_ok && getenv("RAMX_NO_CP_DEVICE") == NULL && ramx_cp_max_family(a.W, a.go, a.ge, d->tab, L) > 0)
       {
         int dev = 0, cus = 0, k = 0, th = 0, nb = 0, vwf = 0;
         HIPCHK(hipGetDevice(&dev));
@@ -1657,6 +1658,7 @@ extern "C" int ramx_dev_run_direction(ramx_dev *d, ramx_run_info *info)
       bool accepted = false;      // the launch call went through
       auto launch = [&]() -> int
       {
+        { const int prc = pack_rest(d); if (prc != RAMX_OK) return prc; }      // this kernel reads the whole window
         CPArgs ca;
         memset(&ca, 0, sizeof(ca));
         ca.bases = d->d_bases; ca.bounds = d->d_bounds; ca.trim = d->d_trim; ca.ctl_out = d->d_ctl; ca.cons_out = d->d_cons;

@@ -190,6 +190,25 @@ def test_seam1_library_cache_sees_in_place_rewrite_and_recycled_buffers():
     y = run_both_directions(gpu_extend, b.cores, buf, p)
     assert_same_result(x[0], x[1], x[2:], y[0], y[1], y[2:], "rewritten in place")
     assert not np.array_equal(x[1], run_both_directions(oracle_extend, a.cores, a.sequence, p)[1])
+    # the same above 64 MiB, where the fingerprint is taken in 16 MiB chunks by worker threads (csrc/ramx_extend.c
+    # fingerprint_large): the family sits at the END of an 80 MB buffer; a rewrite there must be seen
+    pad = 80 * (1 << 20)
+    big = np.full(pad + len(a.sequence), 99, np.int8)
+    big[pad:] = a.sequence
+    ca = a.cores.copy()
+    for f in ("left_pos", "right_pos", "lower", "upper"):
+        getattr(ca, f)[:] += pad
+    x = run_both_directions(oracle_extend, ca, big, p)
+    for rep in range(2):                                    # second pass: served from the device copy
+        y = run_both_directions(gpu_extend, ca, big, p)
+        assert_same_result(x[0], x[1], x[2:], y[0], y[1], y[2:], "large library, pass %d" % rep)
+    cb = b.cores.copy()
+    for f in ("left_pos", "right_pos", "lower", "upper"):
+        getattr(cb, f)[:] += pad
+    big[pad:] = b.sequence
+    x = run_both_directions(oracle_extend, cb, big, p)
+    y = run_both_directions(gpu_extend, cb, big, p)
+    assert_same_result(x[0], x[1], x[2:], y[0], y[1], y[2:], "large library rewritten in place")
     # batch mode: one family of the batch rewritten in place between two calls
     from repeatafterme_amd.datamodel import new_master
     from repeatafterme_amd.extend import extend_batch

@@ -228,16 +228,20 @@ def test_two_ranks_at_a_real_shard_size(no_cp, monkeypatch):
         assert np.array_equal(sc, c.score)
 
 
-@pytest.mark.parametrize("segment", ["0", "48"], ids=["one launch", "pieces of 48 columns"])
-def test_two_ranks_packed_rows_cross_device(segment, monkeypatch):
+@pytest.mark.parametrize("segment,exchanger", [("0", True), ("48", True), ("0", False)],
+                         ids=["one launch", "pieces of 48 columns", "one launch, no exchanger workgroup"])
+def test_two_ranks_packed_rows_cross_device(segment, exchanger, monkeypatch):
     """The packed-row kernel on the cross-device route: each rank runs its first rows on the int32 kernel, hands the sums of the
     next row over to the packed kernel (a launch that starts with this device's sums only: the exchange of that row follows), and
-    -- second case -- continues in pieces of 48 columns, every piece starting the same way.  2 x 20,000 flanks, results = the
+    -- second case -- continues in pieces of 48 columns, every piece starting the same way; the device's exchange duties are done
+    by a workgroup of their own (third case: by workgroup 0).  2 x 20,000 flanks, results = the
     single-process oracle; `packed_rows` shows the path was taken on every rank."""
     from oracle import pyoracle as po
     from repeatafterme_amd.datamodel import new_master
     from repeatafterme_amd.synth import synth_family
     monkeypatch.setenv("RAMX_PK_SEGMENT", segment)
+    if not exchanger:
+        monkeypatch.setenv("RAMX_NO_PK_EXCHANGER", "1")     # workgroup 0 forwards the rank's totals (what a full device does)
     world, shape, W = 2, (40000, 200, 150), 40
     out = mp.Manager().dict()
     mp.spawn(_worker, args=(world, _free_port(), out, True, W, "device", None, True, None, shape), nprocs=world, join=True)
