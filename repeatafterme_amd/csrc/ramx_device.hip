@@ -138,6 +138,7 @@ struct ramx_dev
   ramx_row_verbose_cb verbose_cb; void *verbose_user;   // -vvvv: per-row candidate trace (per-column launches, full candidate recurrence)
   signed char *d_dbg_codes; int2 *d_dbg_best; size_t cap_dbg_codes, cap_dbg_best;
   int *d_dbg_cand; int2 *d_dbg_gap; size_t cap_dbg_cand, cap_dbg_gap;
+  int *d_dbg_band; size_t cap_dbg_band; int verbose_band;      // -vvvvv: every cell of the candidate rows
   CpDevDesc *d_devdesc; size_t cap_devdesc;       // device-wide cell-parallel launches: one descriptor per workgroup
   PShard *d_vote_sets; size_t cap_vote_sets; unsigned *d_err_sets; size_t cap_err_sets;   // batch mode: per-set vote / error words
   int packed_kw;       // words of every window packed so far (begin_direction packs the first piece, see pack_rest)
@@ -227,7 +228,7 @@ extern "C" void ramx_dev_destroy(ramx_dev *d)
     (void)hipEventDestroy(d->cls_ready);
   }
   if (d->devbox) (void)hipFree(d->devbox);
-  (void)hipFree(d->d_fam); (void)hipFree(d->d_famctl); (void)hipFree(d->d_cpstate); (void)hipFree(d->d_dbg_codes); (void)hipFree(d->d_dbg_best); (void)hipFree(d->d_dbg_cand); (void)hipFree(d->d_dbg_gap); (void)hipFree(d->d_devdesc); (void)hipFree(d->d_vote_sets); (void)hipFree(d->d_err_sets);
+  (void)hipFree(d->d_fam); (void)hipFree(d->d_famctl); (void)hipFree(d->d_cpstate); (void)hipFree(d->d_dbg_codes); (void)hipFree(d->d_dbg_best); (void)hipFree(d->d_dbg_cand); (void)hipFree(d->d_dbg_gap); (void)hipFree(d->d_dbg_band); (void)hipFree(d->d_devdesc); (void)hipFree(d->d_vote_sets); (void)hipFree(d->d_err_sets);
   if (d->hostbox_mirror) (void)hipFree(d->hostbox_mirror);
   if (d->d_peer) (void)hipFree(d->d_peer);
   for (int i = 0; i < 2; i++) if (d->ev_chk[i]) (void)hipEventDestroy(d->ev_chk[i]);
@@ -1555,7 +1556,13 @@ extern "C" int ramx_dev_run_direction(ramx_dev *d, ramx_run_info *info)
         HIPCHK(hipMemcpy(gaps.data(), d->d_dbg_gap, (size_t)d->Nx * sizeof(int2), hipMemcpyDeviceToHost));
       }
       for (int i = 0; i < d->Nx; i++) { gfl[2 * i] = gaps[i].x; gfl[2 * i + 1] = gaps[i].y; }
-      d->verbose_cb(r, besta, d->Nx, bs.data(), bi.data(), gfl.data(), cand.data(), d->verbose_user);
+      std::vector<int32_t> band;
+      if (d->verbose_band && d->Nx)
+      {
+        band.resize((size_t)d->Nx * 8 * Bt);
+        HIPCHK(hipMemcpy(band.data(), d->d_dbg_band, band.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+      }
+      d->verbose_cb(r, besta, d->Nx, bs.data(), bi.data(), gfl.data(), cand.data(), band.empty() ? NULL : band.data(), d->verbose_user);
     }
     return RAMX_OK;
   };
@@ -1564,7 +1571,7 @@ extern "C" int ramx_dev_run_direction(ramx_dev *d, ramx_run_info *info)
     int trc;
     if ((trc = ensure(&d->d_dbg_best, &d->cap_dbg_best, (size_t)d->Np * sizeof(int2))) != RAMX_OK) return trc;
     ka.dbg_best = d->d_dbg_best;
-    ka.dbg_codes = NULL; ka.dbg_cand = NULL; ka.dbg_gap = NULL;
+    ka.dbg_codes = NULL; ka.dbg_cand = NULL; ka.dbg_gap = NULL; ka.dbg_band = NULL;
     if (d->trace_cb)
     {
       if ((trc = ensure(&d->d_dbg_codes, &d->cap_dbg_codes, (size_t)d->Np * Bt)) != RAMX_OK) return trc;
@@ -1575,6 +1582,11 @@ extern "C" int ramx_dev_run_direction(ramx_dev *d, ramx_run_info *info)
       if ((trc = ensure(&d->d_dbg_cand, &d->cap_dbg_cand, (size_t)d->Np * 16 * sizeof(int))) != RAMX_OK) return trc;
       if ((trc = ensure(&d->d_dbg_gap, &d->cap_dbg_gap, (size_t)d->Np * sizeof(int2))) != RAMX_OK) return trc;
       ka.dbg_cand = d->d_dbg_cand; ka.dbg_gap = d->d_dbg_gap;
+      if (d->verbose_band)
+      {
+        if ((trc = ensure(&d->d_dbg_band, &d->cap_dbg_band, (size_t)d->Np * 8 * Bt * sizeof(int))) != RAMX_OK) return trc;
+        ka.dbg_band = d->d_dbg_band;
+      }
     }
     return RAMX_OK;
   };
@@ -2062,6 +2074,14 @@ extern "C" int ramx_dev_set_row_verbose(ramx_dev *d, ramx_row_verbose_cb cb, voi
   if (!d) return RAMX_ERR_NO_DEVICE;
   d->verbose_cb = cb;
   d->verbose_user = user;
+  return RAMX_OK;
+}
+
+extern "C" int ramx_dev_set_verbose_band(ramx_dev *d, int on)
+{
+  if (!d) d = ramx_default_device();
+  if (!d) return RAMX_ERR_NO_DEVICE;
+  d->verbose_band = on ? 1 : 0;
   return RAMX_OK;
 }
 

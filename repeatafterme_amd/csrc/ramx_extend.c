@@ -166,10 +166,86 @@ struct verbose_ctx
   int *high;                       /* overall_sequence_high_score per flank */
   int32_t *cand_prev;              /* [nx][16]: the candidate rows of the row about to be reported */
   int max_ext, max_row;
+  /* -vvvvv (VERBOSE >= 12): every cell of those candidate rows (ram_extend.c:1013-1024) and the sequence around the edge of
+   * every core (:1066, report.c printExtensionRegion) */
+  int level;
+  int32_t *band_prev;              /* [nx][4][2W+1][2] */
+  const ramx_flat_cores *cores;
+  const int8_t *sequence;          /* one byte per base, or NULL: */
+  const ramx_packed_library *packed;
+  uint64_t seq_len;
+  const int32_t *seq_idx;          /* per core: its record of the library (NULL: the caller came through ramx_extend_flat) */
+  const uint64_t *boundaries;
 };
+/* set by ramx_extend_alignment for the duration of a call: which record a core belongs to, and the records' ends */
+static const int32_t *g_edge_seq_idx = NULL;
+static const uint64_t *g_edge_boundaries = NULL;
+
+static char trace_num_to_char(int8_t z);
+static int edge_code(const struct verbose_ctx *t, int64_t p, int complement)
+{
+  int c = RAMX_SYM_N;
+  if (p >= 0 && (uint64_t)p < t->seq_len)
+  {
+    if (t->sequence) c = t->sequence[p];
+    else if (t->packed) { char b = RAMX_SYM_N; (void)ramx_packed_decode(t->packed, (uint64_t)p, 1, &b); c = (int8_t)b; }
+  }
+  if (complement && c >= 0 && c < 8) c = (c & 4) | (3 - (c & 3));       /* A<->T, C<->G, case kept (sequence.c:1141-1160) */
+  return c;
+}
+
+/* The line report.c:20-150 prints for a core at VERBOSE >= 12: ten bases on the core side of the last aligned position, that
+ * base, and the bases the extension is about to walk into -- '*' on a record's end, blanks beyond it; minus-strand cores read
+ * the other way round and complemented; right extensions put the core first, left extensions last.  (One quirk is part of the
+ * format: a left extension of a minus-strand core shows nine bases ahead, not ten.) */
+static void print_edge_region(const struct verbose_ctx *t, int n, int row)
+{
+  const int sidx = t->seq_idx ? t->seq_idx[n] : 0;
+  const int64_t lo = (t->boundaries && sidx > 0) ? (int64_t)t->boundaries[sidx - 1] : 0;
+  const int64_t up = t->boundaries ? (int64_t)t->boundaries[sidx] : (int64_t)t->seq_len;
+  const int minus = t->cores->orient[n] ? 1 : 0;
+  /* the walk goes up the library for (right, +) and (left, -), down for the other two */
+  const int up_walk = (t->direction != 0) != (minus != 0);
+  const int64_t edge = t->direction ? t->cores->right_pos[n] : t->cores->left_pos[n];
+  const int64_t last = up_walk ? edge + row + 1 : edge - row - 1;
+  char core[16], ext[16];
+  int nc = 0, ne = 0;
+  /* core side: behind the walk; written in reading order of the printed strand */
+  for (int k = 10; k >= 1; k--)
+  {
+    /* position k steps behind `last` */
+    const int64_t p = up_walk ? last - k : last + k;
+    char ch;
+    if (up_walk) ch = (p == lo) ? '*' : (p < lo) ? ' ' : trace_num_to_char((int8_t)edge_code(t, p, minus));
+    else ch = (p == up) ? '*' : (p > up) ? ' ' : trace_num_to_char((int8_t)edge_code(t, p, minus));
+    core[nc++] = ch;
+  }
+  const int ahead = (!t->direction && minus) ? 9 : 10;
+  for (int k = 1; k <= ahead; k++)
+  {
+    const int64_t p = up_walk ? last + k : last - k;
+    char ch;
+    if (up_walk) ch = (p == up) ? '*' : (p > up) ? ' ' : trace_num_to_char((int8_t)edge_code(t, p, minus));
+    else ch = (p == lo) ? '*' : (p < lo) ? ' ' : trace_num_to_char((int8_t)edge_code(t, p, minus));
+    ext[ne++] = ch;
+  }
+  core[nc] = '\0'; ext[ne] = '\0';
+  const char mid = trace_num_to_char((int8_t)edge_code(t, last, minus));
+  printf("C_EDGE: sIdx=%d, orient=%d, pos=%ld: ", sidx, minus, (long)(last - lo + 1));
+  if (t->direction) printf("%s] {%c} %s\n", core, mid, ext);
+  else
+  {
+    /* left extensions: what lies ahead first (furthest base first), the core side behind the bracket (nearest base first) */
+    char r1[16], r2[16];
+    for (int k = 0; k < ne; k++) r1[k] = ext[ne - 1 - k];
+    for (int k = 0; k < nc; k++) r2[k] = core[nc - 1 - k];
+    r1[ne] = '\0'; r2[nc] = '\0';
+    printf("%s {%c} [%s\n", r1, mid, r2);
+  }
+}
 
 static void verbose_row(int32_t row, int32_t besta, int32_t n_flanks, const int32_t *best_score, const int32_t *best_idx,
-                        const int32_t *gfl, const int32_t *cand, void *user)
+                        const int32_t *gfl, const int32_t *cand, const int32_t *band, void *user)
 {
   struct verbose_ctx *t = (struct verbose_ctx *)user;
   static const char base[4] = { 'A', 'C', 'G', 'T' };
@@ -185,6 +261,16 @@ static void verbose_row(int32_t row, int32_t besta, int32_t n_flanks, const int3
       {
         const int32_t *c = t->cand_prev + (size_t)i * 16;
         printf(t->direction ? "RIGHT ROW %d with '%c': n = %d\n" : "LEFT ROW %d with '%c': n = %d\n", row, base[a], t->core_index[i]);
+        if (t->level >= 12 && t->band_prev)
+        {
+          const int Bw = 2 * t->W + 1;
+          const int32_t *bp = t->band_prev + ((size_t)i * 4 + a) * Bw * 2;
+          printf("    Gap: ");
+          for (int j = 0; j < Bw; j++) printf(" %d", bp[2 * j + 1]);
+          printf("\n    Sub: ");
+          for (int j = 0; j < Bw; j++) printf(" %d", bp[2 * j]);
+          printf("\n");
+        }
         int b = c[a];
         const int col = row + c[4 + a] - t->W, hi = t->high[i];
         if (b < 0) printf("  best score = %d @ column %d -- max(0,best_score) = 0!, prev best score = %d\n", b, col, hi);
@@ -194,6 +280,7 @@ static void verbose_row(int32_t row, int32_t besta, int32_t n_flanks, const int3
         if (b >= hi + t->cap) sum += b;
         else { printf(" **CAPPED** contributing = %d", hi + t->cap); sum += hi + t->cap; }
         printf("\n");
+        if (t->level >= 12 && t->cores) print_edge_region(t, t->core_index[i], row);
       }
       printf("  Total Score for '%c' = %d\n", base[a], sum);
       if (sum > curr) { curr = sum; chosen = a; }
@@ -221,6 +308,7 @@ static void verbose_row(int32_t row, int32_t besta, int32_t n_flanks, const int3
       printf("                     extensions since last max score %d\n", abs(row - t->max_row));
   }
   memcpy(t->cand_prev, cand, sizeof(int32_t) * 16 * (size_t)nx);
+  if (t->band_prev && band) memcpy(t->band_prev, band, sizeof(int32_t) * 8 * (size_t)(2 * t->W + 1) * (size_t)nx);
 }
 
 static char trace_num_to_char(int8_t z)      /* sequence.c:1091-1111 */
@@ -368,6 +456,14 @@ static int extend_flat_impl(int direction, ramx_flat_cores *c, const int8_t *seq
     vctx.high = (int *)calloc((size_t)(nx > 0 ? nx : 1), sizeof(int));
     vctx.cand_prev = (int32_t *)calloc((size_t)(nx > 0 ? nx : 1) * 16, sizeof(int32_t));
     vctx.max_ext = 0; vctx.max_row = -1;
+    vctx.level = g_verbose;
+    if (g_verbose >= 12)
+    {
+      vctx.band_prev = (int32_t *)calloc((size_t)(nx > 0 ? nx : 1) * 8 * (size_t)(2 * W + 1), sizeof(int32_t));
+      vctx.cores = c; vctx.sequence = sequence; vctx.packed = packed; vctx.seq_len = packed ? packed->length : seq_len;
+      vctx.seq_idx = g_edge_seq_idx; vctx.boundaries = g_edge_boundaries;
+      ramx_dev_set_verbose_band(d, 1);
+    }
     ramx_dev_set_row_verbose(d, verbose_row, &vctx);
   }
   if (g_trace_file == NULL && !verbose_rows && nx == 0 && getenv("RAMX_NO_HOST_EMPTY") == NULL)
@@ -421,7 +517,7 @@ static int extend_flat_impl(int direction, ramx_flat_cores *c, const int8_t *seq
     if (rc == RAMX_OK) rc = ramx_dev_run_direction(d, info);
     SEAM1_PHASE("run direction");
     if (g_trace_file != NULL) ramx_dev_set_row_trace(d, NULL, NULL);
-    if (verbose_rows) { ramx_dev_set_row_verbose(d, NULL, NULL); free(vctx.high); free(vctx.cand_prev); vctx.high = NULL; vctx.cand_prev = NULL; }
+    if (verbose_rows) { ramx_dev_set_row_verbose(d, NULL, NULL); ramx_dev_set_verbose_band(d, 0); free(vctx.high); free(vctx.cand_prev); free(vctx.band_prev); vctx.high = NULL; vctx.cand_prev = NULL; vctx.band_prev = NULL; }
     if (rc != RAMX_OK) { free(cons); free(map); free(fl); return rc; }
     th = (int32_t *)malloc(sizeof(int32_t) * (nx > 0 ? nx : 1));
     tp = (int32_t *)malloc(sizeof(int32_t) * (nx > 0 ? nx : 1));
@@ -471,14 +567,30 @@ int ramx_extend_alignment(int direction, struct coreAlignment *coreAlign, int **
     if (direction) printf("extend_alignment(right): Called with %d edges\n", N);
     else printf("extend_alignment(left): Called with %d edges\n", N);
   }
+  if (g_verbose > 12)
+    fprintf(stderr, "RAMExtend(ramx): the per-cell lines compute_nw_row prints above -vvvvv (bnw_extend.c, VERBOSE > 12) are not "
+                    "produced by the device path; the band dumps of -vvvvv and the per-row lines of -vvvv are\n");
   if (g_verbose >= 12)
-    fprintf(stderr, "RAMExtend(ramx): the band dumps of -vvvvv and above (ram_extend.c:949-959, 1013-1024) are not produced by the "
-                    "device path; the per-row lines of -vvvv are\n");
+  {
+    /* ram_extend.c:949-959: the boundary row of every core, as initialised at :909-946 */
+    for (int k = 0; k < N; k++)
+    {
+      printf("SW Matrix Boundary Conditions ( n = %d ):\n", k);
+      for (int st = 0; st < 2; st++)
+      {
+        printf(st == 0 ? "  GAP: " : "\n  SUB: ");
+        for (int o = -BANDWIDTH; o <= BANDWIDTH; o++)
+          printf(" %d", o == 0 ? 0 : (o < 0 ? -o : o) * scoreParams->gapextn + scoreParams->gapopen);
+      }
+      printf("\n");
+    }
+  }
 
   const int n = N > 0 ? N : 0;
   int64_t *i64 = (int64_t *)malloc(sizeof(int64_t) * 4 * (n + 1));
   int8_t *i8 = (int8_t *)malloc(3 * (n + 1));
   int32_t *i32 = (int32_t *)calloc(3 * (n + 1), sizeof(int32_t));
+  int32_t *sidx = (int32_t *)calloc((size_t)n + 1, sizeof(int32_t));      /* -vvvvv: the record of every core (print_edge_region) */
   ramx_flat_cores fc;
   fc.left_pos = i64; fc.right_pos = i64 + n; fc.lower = i64 + 2 * n; fc.upper = i64 + 3 * n;
   fc.orient = i8; fc.left_ext = i8 + n; fc.right_ext = i8 + 2 * n;
@@ -499,8 +611,10 @@ int ramx_extend_alignment(int direction, struct coreAlignment *coreAlign, int **
     fc.left_len[k] = cc->leftExtensionLen;
     fc.right_len[k] = cc->rightExtensionLen;
     fc.score[k] = cc->score;
+    sidx[k] = cc->seqIdx;
   }
   fc.n = k;
+  g_edge_seq_idx = sidx; g_edge_boundaries = seqLib->boundaries;
 
   int32_t *mflat = (int32_t *)malloc(sizeof(int32_t) * 100 * 100);
   /* only [0..3][0..7,99] is defined in the reference's matrix (score_system.c:187-395) */
@@ -558,7 +672,8 @@ int ramx_extend_alignment(int direction, struct coreAlignment *coreAlign, int **
     cc->rightExtensionLen = fc.right_len[k];
     cc->score = fc.score[k];
   }
-  free(i64); free(i8); free(i32); free(mflat);
+  g_edge_seq_idx = NULL; g_edge_boundaries = NULL;
+  free(i64); free(i8); free(i32); free(sidx); free(mflat);
   g_trace_file = NULL;
   return ret;
 }

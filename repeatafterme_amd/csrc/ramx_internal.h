@@ -44,8 +44,11 @@ void ramx_parallel_for(int n, long min_items, ramx_range_fn fn, void *user);
  * row + 1: cand[i][16] = best[4], best cell[4], gap of the first cell[4], gap of the last cell[4].  d == NULL: seam 1's
  * session.  A debugging aid: slow by construction. */
 typedef void (*ramx_row_verbose_cb)(int32_t row, int32_t besta, int32_t n_flanks, const int32_t *best_score, const int32_t *best_idx,
-                                    const int32_t *gap_first_last /* [n][2] */, const int32_t *cand /* [n][16] */, void *user);
+                                    const int32_t *gap_first_last /* [n][2] */, const int32_t *cand /* [n][16] */,
+                                    const int32_t *band /* -vvvvv: [n][4][2W+1][2] = (sub, gap) of every candidate cell; else NULL */, void *user);
 int ramx_dev_set_row_verbose(ramx_dev *d, ramx_row_verbose_cb cb, void *user);
+/* -vvvvv (ram_extend.c:1013-1024): the callback also gets every cell of the four candidate rows */
+int ramx_dev_set_verbose_band(ramx_dev *d, int on);
 
 /* process-wide device session used by seam 1 (created on first use) */
 ramx_dev *ramx_default_device(void);

@@ -47,6 +47,7 @@ struct KArgs
   // compute_nw_row calls see them (ram_extend.c:992-1062) -- best cell value, its band cell, and the gap state of the row's
   // first and last cell (the **OUT_OF_SEQ** tests of :1036-1038 and :1134-1136) -- and the same two gap states of row r
   int *dbg_cand;             // [Np][16]: best[4], cell[4], gap_first[4], gap_last[4]; NULL: not wanted
+  int *dbg_band;             // -vvvvv: [Np][4][2W+1][2]: every cell (sub, gap) of the four candidate rows; NULL: not wanted
   int2 *dbg_gap;             // [Np]: gap state of row r's first / last cell
 };
 
@@ -288,6 +289,8 @@ struct LaneDP
   int bestA[4];
   // -vvvv trace only (DBG && CHAIN): where each candidate row's best cell is, gap states of the rows' end cells
   int jA[4], gA0[4], gAL[4], gF0, gFL;
+  // -vvvvv trace only: where the candidate rows' cells go (ram_extend.c:1013-1024 prints them): [4][2W+1][2] = (sub, gap); NULL: not wanted
+  int *band;
 };
 
 // Uniform (scalar) per-step quantities.
@@ -413,6 +416,11 @@ __device__ __forceinline__ void band_step(const int go, const int ge, const int 
         if (imax(subA, gapA) > L.bestA[c]) L.jA[c] = u.j - 1;
         if (u.j - 1 == 0) L.gA0[c] = gapA;
         if (u.j - 1 == 2 * W) L.gAL[c] = gapA;
+        if (L.band != nullptr)
+        {
+          int *o = L.band + ((size_t)c * (2 * W + 1) + (u.j - 1)) * 2;
+          o[0] = subA; o[1] = gapA;
+        }
       }
       L.bestA[c] = imax3(L.bestA[c], subA, gapA);
       L.eA[c] = imax(subA + go, gapA) + ge;

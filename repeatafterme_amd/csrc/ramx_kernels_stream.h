@@ -106,6 +106,7 @@ __global__ __launch_bounds__(BLOCK) void ramx_column_kernel(const KArgs a)
 #pragma unroll
     for (int c = 0; c < 4; c++) { D.eA[c] = NEG; D.bestA[c] = NEG; D.jA[c] = 0; D.gA0[c] = NEG; D.gAL[c] = NEG; }
     D.gF0 = NEG; D.gFL = NEG;
+    D.band = (DBG && CHAIN && a.dbg_band != NULL) ? a.dbg_band + (size_t)n * 8 * B : nullptr;
     int high = 0, pos = 0;
     // wave-uniform choice: do all 64 flanks cover every cell of both rows?  (steps 0..B)
     const bool all_in = !INIT && !DBG && __all((n >= a.Nx) || ((jlo <= 0) && (jhi >= B)));   // padding lanes: all-N stream, masked vote

@@ -100,6 +100,15 @@ VERBOSE_CASES = [
     ("g1_vvvv_rs", "genome_1", ["-matrix", "repeatscout", "-match", "2", "-mismatch", "-2", "-gap", "-6", "-L", "50", "-bandwidth", "10",
                                 "-vvvv"]),
     ("g2_vvvv_w3", "genome_2", ["-bandwidth", "3", "-matrix", "18p43g", "-L", "80", "-cappenalty", "-40", "-vvvv"]),
+    # -vvvvv (VERBOSE 12): + the boundary rows (ram_extend.c:949-959), every cell of every candidate row (:1013-1024) and the
+    # sequence around every core's edge (:1066, report.c printExtensionRegion)
+    ("t2_v5", "extension-test2", ["-bandwidth", "10", "-L", "30", "-vvvvv"]),
+    ("g3_v5", "genome_3", ["-bandwidth", "20", "-matrix", "14p43g", "-L", "40", "-vvvvv"]),
+    ("ov_v5", "genome_ov", ["-L", "30", "-bandwidth", "14", "-vvvvv", "-cappenalty", "-10"]),
+    # (bandwidth >= 10 in all of them: with a narrower band the ten bases printExtensionRegion shows ahead of a core of the FIRST
+    # record reach in front of the library in the last rows, where the reference computes `lastAligned + j` in uint64 and reads
+    # the byte in front of the sequence array -- undefined, not reproducible; ramx prints a blank there)
+    ("g2_v5_w10", "genome_2", ["-bandwidth", "10", "-matrix", "18p43g", "-L", "30", "-cappenalty", "-40", "-vvvvv"]),
 ]
 
 

@@ -225,7 +225,9 @@ def test_cli_vvvv_per_row_lines_match_reference(case):
     ` **CAPPED** contributing = ...`, the totals per candidate, the chosen base, and the "Alignment Extension" block with
     its float columns and the new-maximum / extensions-since lines -- written from the device's candidate-row trace (full
     recurrence).  Whole stdout against the reference binary's, both directions; five cases incl. short flanks
-    (OUT_OF_SEQ), a tight cap (CAPPED), repeatscout scoring and bandwidth 3."""
+    (OUT_OF_SEQ), a tight cap (CAPPED), repeatscout scoring and bandwidth 3.  The `*_v5` cases run `-vvvvv` (VERBOSE 12): in
+    addition the boundary rows (ram_extend.c:949-959), EVERY cell (gap and substitution state) of every candidate row
+    (:1013-1024) and the sequence around every core's edge (report.c printExtensionRegion) -- four cases, both strands."""
     import gzip
     argv = open(os.path.join(G, "cli", case, "argv")).read().split()
     stem = open(os.path.join(G, "cli", case, "stem")).read().strip()
