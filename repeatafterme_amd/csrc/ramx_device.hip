@@ -361,6 +361,7 @@ extern "C" int ramx_dev_begin_direction(ramx_dev *d, const ramx_flank *flanks, i
   if (p->bandwidth < 0 || p->L < 0) { ramx_set_error("bandwidth and L must be >= 0"); return RAMX_ERR_ARG; }
   if (!p->matrix) { ramx_set_error("scoring matrix missing"); return RAMX_ERR_ARG; }
   HIPCHK(hipSetDevice(d->ordinal));
+  rt_mark(NULL);
   const int W = p->bandwidth, Q = W + 1;
   const int Nx = n_flanks;
   const int Np = ((Nx + 63) / 64) * 64 > 0 ? ((Nx + 63) / 64) * 64 : 64;
@@ -394,7 +395,9 @@ extern "C" int ramx_dev_begin_direction(ramx_dev *d, const ramx_flank *flanks, i
     d->cap_state = state_bytes;
   }
   if ((rc = ensure(&d->d_cons, &d->cap_cons, (size_t)p->L + 16))) return rc;
+  rt_mark("begin: buffers");
   if (Nx) HIPCHK(hipMemcpyAsync(d->d_flanks, flanks, (size_t)Nx * sizeof(ramx_flank), hipMemcpyHostToDevice, d->stream));
+  rt_mark("begin: flanks to the device (enqueued)");
   {
     if (d->pack_busy) { HIPCHK(hipStreamWaitEvent(d->stream, d->pack_done, 0)); d->pack_busy = 0; }    // (a piece of the direction before still in flight)
     const int seg = pk_segment_columns(p->L, p->when_to_stop);
@@ -404,7 +407,9 @@ extern "C" int ramx_dev_begin_direction(ramx_dev *d, const ramx_flank *flanks, i
   }
   HIPCHK(hipMemsetAsync(d->d_sums, 0, 3 * NSHARD * 4 * sizeof(long long), d->stream));
   HIPCHK(hipMemsetAsync(d->d_cons, 0, (size_t)p->L + 16, d->stream));
+  rt_mark("begin: pack of the first piece enqueued");
   HIPCHK(hipStreamSynchronize(d->stream));
+  rt_mark("begin: synchronised");
   // the cell-parallel kernels take flanks that are empty or start at or before the first base behind the core edge
   d->cp_flanks_ok = 1;
   for (int i = 0; i < Nx; i++)
