@@ -335,6 +335,12 @@ template <int W, int BLOCK>
 __global__ __launch_bounds__(BLOCK, BLOCK / 256) void ramx_packed_kernel(const PKArgs a)
 {
   constexpr int NP = PkCfg<W>::NP, NW = PkCfg<W>::NW, NG = PkCfg<W>::NG, Q = PkCfg<W>::Q, WPB = BLOCK / 64;
+  // 320 threads = four band waves (one per SIMD) and a VOTE WAVE without flanks: with one wave per SIMD all band waves finish
+  // their row together, and the poll of the vote (a round trip to the memory fabric, ~0.9 us with the fold and the stop rule)
+  // by one of them afterwards was part of every column; the fifth wave has polled and decided by the time they arrive.  (With
+  // two waves per SIMD the older wave of SIMD 0 has that time anyway, and a ninth wave has no registers.)
+  constexpr bool VW = (BLOCK % 256) != 0;
+  constexpr int BW = VW ? WPB - 1 : WPB, VOTER = VW ? BW : 0;
   // rows may run one unconfirmed step ahead of the vote where a second copy of the row fits the registers
   constexpr bool SPEC = W <= 40;
   struct Smem      // tables first: their LDS addresses must fit the 16-bit offset field of the ds_read that uses them
@@ -351,8 +357,8 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 256) void ramx_packed_kernel(const P
   };
   __shared__ __attribute__((aligned(16))) Smem sm;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int tile = blockIdx.x * WPB + wave;
-  const bool live = tile < (a.Np >> 6);
+  const int tile = blockIdx.x * BW + wave;
+  const bool live = wave < BW && tile < (a.Np >> 6);
   const int n = (live ? tile : 0) * 64 + lane;
   int4 *S = a.S + (size_t)(live ? tile : 0) * Q * 64 + lane;
   const int2 bd = a.bounds[n];
@@ -554,7 +560,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 256) void ramx_packed_kernel(const P
     // last arriver of this column leaves for the next one (sm.word[par] = { decision(r), guess(r+1) }: one LDS read per column).
     auto decide = [&]() __attribute__((always_inline)) -> bool
     {
-      if (wave == 0)
+      if (wave == VOTER)
       {
         long long v[4];
         int lv = lane;
@@ -659,6 +665,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 256) void ramx_packed_kernel(const P
       if constexpr (SPEC)
       {
 #ifndef PKB_PROBE_NO_BACKUP      // timing probe (wrong results after a wrong guess)
+        if (live)         // (a wave without flanks -- the vote wave of the 320-thread shape, padding tiles -- has nothing to keep)
         static_for([&](auto kc) __attribute__((always_inline)) { constexpr int k = decltype(kc)::value; Rb[k] = R[k]; myEb[k] = E[k]; }, std::make_integer_sequence<int, NP>{});
 #else
         Rb[0] = R[0];
@@ -787,7 +794,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 256) void ramx_packed_kernel(const P
       // ---- the row was computed on the guess: what does the vote say? -------------------------------------------------
       if (!decide()) { gave_up = true; break; }
       const bool right = besta == wsel;
-      if (wave == 0)
+      if (wave == VOTER)
       {
         // the speculative totals are complete (every wave arrived before the barrier): send them if they stand, clear them
         if (lane < 4)
@@ -816,6 +823,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 256) void ramx_packed_kernel(const P
       // guessed wrong: back to row r-1 and the records behind it
       if constexpr (SPEC)
       {
+        if (live)
         static_for([&](auto kc) __attribute__((always_inline)) { constexpr int k = decltype(kc)::value; R[k] = Rb[k]; E[k] = myEb[k]; }, std::make_integer_sequence<int, NP>{});
         high = high_b; pos = pos_b; prevBest = prev_b; pbase = pbase_b;
       }
@@ -870,7 +878,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 256) void ramx_packed_kernel(const P
     // (recomputed from an opaque copy of the lane index: the pointer would otherwise stay in two registers through the whole loop)
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
-    int4 *S3 = a.S + (size_t)(blockIdx.x * WPB + (tid >> 6)) * Q * 64 + (tid & 63);
+    int4 *S3 = a.S + (size_t)(blockIdx.x * BW + (tid >> 6)) * Q * 64 + (tid & 63);
     auto val = [&](int half, int j, bool is_e) __attribute__((always_inline)) -> int
     {
       if (j > jh) { const int f = j < W ? edge : SENT; return is_e ? f + a.ge : f; }

@@ -55,10 +55,16 @@ static int pk_shape(int tiles, int *block, int *blocks)
 {
   int cap = 0, rc;
   *block = 0; *blocks = 0;
-  // one wave per SIMD while the flank set allows it, two above
-  if ((rc = pk_capacity<W, 256>(&cap)) != RAMX_OK) return rc;
+  // one wave per SIMD while the flank set allows it (four band waves and a vote wave without flanks: 320 threads;
+  // RAMX_PK_NO_VW=1: the four band waves alone, A/B), two above
+  // (W = 80: the row's 162 registers leave no room for a second wave on SIMD 0 -- its 256-thread workgroups have the register
+  // file of a SIMD per wave -- so no vote wave there)
+  const bool vw = W <= 40 && getenv("RAMX_PK_NO_VW") == NULL;
+  if constexpr (W <= 40) rc = vw ? pk_capacity<W, 320>(&cap) : pk_capacity<W, 256>(&cap);
+  else rc = pk_capacity<W, 256>(&cap);
+  if (rc != RAMX_OK) return rc;
   if (getenv("RAMX_PK_NO_256") != NULL) cap = 0;
-  if ((tiles + 3) / 4 <= cap) { *block = 256; *blocks = (tiles + 3) / 4; return RAMX_OK; }
+  if ((tiles + 3) / 4 <= cap) { *block = vw ? 320 : 256; *blocks = (tiles + 3) / 4; return RAMX_OK; }
   if constexpr (W <= 40)       // W = 80: 162 row registers leave no room for a second wave per SIMD (it would run from scratch memory)
   {
     if ((rc = pk_capacity<W, 512>(&cap)) != RAMX_OK) return rc;
@@ -73,6 +79,8 @@ int ramx_pk_capacity(int W, int block, int *cap)
   *cap = 0;
   if (block == 256)
     switch (W) { case 14: return pk_capacity<14, 256>(cap); case 20: return pk_capacity<20, 256>(cap); case 40: return pk_capacity<40, 256>(cap); case 80: return pk_capacity<80, 256>(cap); }
+  if (block == 320)
+    switch (W) { case 14: return pk_capacity<14, 320>(cap); case 20: return pk_capacity<20, 320>(cap); case 40: return pk_capacity<40, 320>(cap); }
   if (block == 512)
     switch (W) { case 14: return pk_capacity<14, 512>(cap); case 20: return pk_capacity<20, 512>(cap); case 40: return pk_capacity<40, 512>(cap); }
   return RAMX_OK;
@@ -96,6 +104,11 @@ static int pk_launch(hipStream_t st, int block, int blocks, const PKArgs &a)
 {
   const int grid = blocks + (a.xblock != 0 ? 1 : 0);       // + the exchanger (ramx_kernels_packed.h)
   if (block == 256) hipLaunchKernelGGL((ramx_packed_kernel<W, 256>), dim3(grid), dim3(256), 0, st, a);
+  else if (block == 320)
+  {
+    if constexpr (W <= 40) hipLaunchKernelGGL((ramx_packed_kernel<W, 320>), dim3(grid), dim3(320), 0, st, a);
+    else return RAMX_ERR_ARG;
+  }
   else if (block == 512)
   {
     if constexpr (W <= 40) hipLaunchKernelGGL((ramx_packed_kernel<W, 512>), dim3(grid), dim3(512), 0, st, a);
