@@ -135,8 +135,8 @@ typedef struct ramx_run_info
   double  prep_ms;          /* host flatten + H2D + pack kernel (wall clock) */
   int32_t persistent;       /* 1: the whole loop ran as ONE persistent launch (rows resident on chip) */
   int32_t lanes_per_flank;  /* 1: one lane per flank; 2..16: the cell-parallel kernels split a band row over that many lanes */
-  int32_t respeculated_rows; /* device-wide cell-parallel kernel: rows that workgroup 0 computed a second time because its own
-                               guess of the vote was wrong (it runs ahead of the device-wide vote); 0 on every other route */
+  int32_t respeculated_rows; /* device-wide cell-parallel kernel and packed-row kernel: rows that workgroup 0 computed a second time
+                               because its own guess of the vote was wrong (it runs ahead of the device-wide vote); 0 on every other route */
   int32_t packed_rows;      /* columns that ran in the packed-row persistent kernel (two cells per register, int16 relative to a
                                per-flank base: csrc/ramx_kernels_packed.h); 0 on every other route */
   int32_t lean_rows;        /* ... of which the first wave ran as LEAN rows (no candidate rows, no best-cell index) */
@@ -146,8 +146,8 @@ int ramx_extend_flat(int direction, ramx_flat_cores *cores, const int8_t *sequen
                      int8_t *master, const ramx_params *p, ramx_run_info *info);
 
 /* Seam 1 keeps the library on the device between calls, keyed on (pointer, length, 64-bit content fingerprint), so
- * the second direction does not upload it again; libraries above 64 MiB are uploaded on every call instead of being
- * fingerprinted.  The reference has no such state (ram_extend.c reads seqLib->sequence on every call): a caller who
+ * the second direction does not upload it again (libraries above 64 MiB are fingerprinted in chunks by worker threads).
+ * The reference has no such state (ram_extend.c reads seqLib->sequence on every call): a caller who
  * wants to be explicit can drop the device copy with this call. */
 void ramx_invalidate_library(void);
 /* Upload a library ahead of the first extension call (e.g. from a helper thread while the caller still prints its
