@@ -288,3 +288,33 @@ def test_packed_rows_direction_in_pieces(seg, monkeypatch):
         assert np.array_equal(got[1], ref[1]) and np.array_equal(got[2], ref[2]) and np.array_equal(got[3], ref[3])
         for (ca, ha, pa), (cb, hb, pb) in zip(got[4], ref[4]):
             assert np.array_equal(ca, cb) and (ha, pa) == (hb, pb)
+
+
+@pytest.mark.parametrize("W,matrix", [(40, "14p43g"), (20, "25p43g")])
+def test_packed_rows_vote_wave_shape_equals_band_waves_alone(W, matrix, monkeypatch):
+    """Up to 65,536 flanks a workgroup of the packed-row kernel is four band waves and a vote wave WITHOUT flanks (320 threads:
+    the fifth wave polls the vote and runs the stop rule while the others compute); RAMX_PK_NO_VW=1 gives the four band waves
+    alone (256 threads, wave 0 votes after its row).  Same results, same final DP rows, and the oracle's -- with rows ahead of
+    the vote, forced wrong guesses and pieces in both shapes."""
+    import os
+    if not os.environ.get("RAMX_NO_CP_DEVICE"):
+        pytest.skip("the lane-per-flank route is selected by the fixture's RAMX_NO_CP_DEVICE leg")
+    L = 720
+    fs = _two_copy_family(1100, L, W, 60, seed=7300 + W, short_frac=0.05)
+    p = po.Params.named(matrix, bandwidth=W, L=L, when_to_stop=35)
+    x = run_both_directions(oracle_extend, fs.cores, fs.sequence, p)
+    y = run_both_directions(gpu_extend, fs.cores, fs.sequence, p)
+    assert_same_result(x[0], x[1], x[2:], y[0], y[1], y[2:], f"W={W}")
+    ref = _run_device(fs, p, 1, monkeypatch, True)
+    assert ref[0].packed_rows > 0
+    for env in ({"RAMX_PK_NO_VW": "1"}, {"RAMX_PK_NO_VW": "1", "RAMX_TEST_PK_WRONG_EVERY": "3"}, {"RAMX_TEST_PK_WRONG_EVERY": "2"},
+                {"RAMX_PK_SEGMENT": "64"}, {"RAMX_PK_NO_VW": "1", "RAMX_PK_SEGMENT": "64"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        got = _run_device(fs, p, 1, monkeypatch, True)
+        for k in env:
+            monkeypatch.delenv(k)
+        assert (got[0].ret, got[0].rows_executed, got[0].limit_warning) == (ref[0].ret, ref[0].rows_executed, ref[0].limit_warning), env
+        assert np.array_equal(got[1], ref[1]) and np.array_equal(got[2], ref[2]) and np.array_equal(got[3], ref[3]), env
+        for (ca, ha, pa), (cb, hb, pb) in zip(got[4], ref[4]):
+            assert np.array_equal(ca, cb) and (ha, pa) == (hb, pb), env
