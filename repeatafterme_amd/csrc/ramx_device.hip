@@ -921,6 +921,10 @@ static int prk_run(ramx_dev *d, const KArgs &a, int L, bool *used)
     ka.lean_p = pa.lean_p; ka.leader_max = pa.leader_max;
     ka.spec_on = getenv("RAMX_NO_PK_SPEC") == NULL ? 1 : 0;
     { const char *we = getenv("RAMX_TEST_PK_WRONG_EVERY"); ka.test_wrong_every = we ? atoi(we) : 0; }
+    // test hook: a span smaller than the scoring system's makes the kernel's own checks (rows at entry, every 16th row) refuse
+    { const char *ts = getenv("RAMX_TEST_PK_SPREAD"); if (ts) ka.spread = atoi(ts); }
+    ka.spread_rows = ka.spread;
+    { const char *ts = getenv("RAMX_TEST_PK_SPREAD_ROWS"); if (ts) ka.spread_rows = atoi(ts); }
     d->last_packed_r0 = pk_r0;
     // The direction runs in pieces of RAMX_PK_SEGMENT columns (one launch each: rows written back, sums of the next row handed
     // over as plain words, control block passed on), so that only the base words a run really reads are ever packed: the
@@ -1859,9 +1863,9 @@ extern "C" int ramx_dev_run_direction(ramx_dev *d, ramx_run_info *info)
     rt_mark("after the launch: control blocks, error word");
     if (c0[0].pad != 0 || c0[1].pad != 0 || errw != 0)
     {
-      if (errw == 2)
-        fprintf(stderr, "ramx: the packed-row kernel refused the rows (a cell outside the span computed for this scoring system); repeating "
-                        "the direction with per-column launches\n");
+      if (errw == 2 || errw == 3)
+        fprintf(stderr, "ramx: the packed-row kernel refused %s (a cell outside the span computed for this scoring system); repeating "
+                        "the direction with per-column launches\n", errw == 3 ? "the rows it was handed" : "a row it computed");
       else
       fprintf(stderr, "ramx: device-wide barrier of the persistent launch timed out (bounded spin); repeating the direction with "
                       "per-column launches\n");

@@ -417,7 +417,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 256) void ramx_packed_kernel(const P
       prk_wait_vote(a, vb, a.sums_in, r == a.r0 ? (a.r0 == 0 ? 1 : 2) : 0, r, lane, (a.nblocks - (lane & (NSHARD - 1)) + NSHARD - 1) / NSHARD, failed, v, true);
       const int fl = __any(failed) ? 1 : 0;
       const int dword = pkb_stop_rule(a, r, v, fl, sm.st, lane);
-      if (fl) { if (lane == 0) __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      if (fl) { if (lane == 0) __hip_atomic_fetch_max(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
       if (lane == 0) a.cons_out[r] = (signed char)(dword & 3);
       if (lane < NSHARD)
       {
@@ -465,7 +465,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 256) void ramx_packed_kernel(const P
     pbase = none ? 0 : bmax;
     // entry check: every in-bounds cell within the span the host computed (else this representation is not safe: give up loudly)
     if (live && !skip && n < a.Nx && !none && (long long)bmax - (long long)bmin > (long long)a.spread)
-      __hip_atomic_store(a.err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_max(a.err, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     int jcut2 = jcut;
     const int4 *S2 = S;
     asm volatile("" : "+v"(jcut2), "+v"(S2));                     // second pass: its own comparisons (the first pass's would be kept in scalar registers)
@@ -574,7 +574,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 256) void ramx_packed_kernel(const P
         if (lane == 0)
         {
           sm.word[par][0] = dword;
-          if (fl) __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (fl) __hip_atomic_fetch_max(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (blockIdx.x == a.xblock && !fl)
         {
@@ -753,6 +753,27 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 256) void ramx_packed_kernel(const P
         const int bestF = jhi < 0 ? SENT : pbase + rel;      // a flank that has run out: every cell holds the sentinel (bnw_extend.c:990-1002)
         for (unsigned long long rest = leaders; rest != 0; rest &= rest - 1)
           pkb_leader_rows<W, BLOCK>(sm.pt, sm.lead[wave], (r + 8) & 7, __builtin_ctzll(rest), pbase, jhi, bestF, w, R, E, bestA, jbest);
+        // Every 16th row the span the host computed for this scoring system (ramx_pk_plan: how far an in-bounds cell can lie below
+        // its row's best cell) is CHECKED against the row, not only assumed: the arithmetic saturates, so a cell outside it would
+        // not wrap but silently stick.  A row outside the span raises error word 2 (3: the rows the launch was handed; the highest word stays); the host repeats the
+        // direction on the per-column route (13 instructions per row on average).
+        if ((r & 15) == 15)
+        {
+          int mn = 0x7fff7fff, jj = jhi;
+          asm volatile("" : "+v"(jj));
+          static_for([&](auto kc) __attribute__((always_inline))
+          {
+            constexpr int k = decltype(kc)::value;
+            int v = R[k];
+            const bool in_hi = 2 * k + 1 < PkCfg<W>::B && 2 * k + 1 <= jj;       // (cell 2W+1 does not exist; cells beyond the flank's end do not count)
+            v = in_hi ? v : ((v & 0xffff) | 0x7fff0000);
+            v = 2 * k <= jj ? v : 0x7fff7fff;
+            mn = pk_i(__builtin_elementwise_min(pk_v(mn), pk_v(v)));
+          }, std::make_integer_sequence<int, NP>{});
+          const pk_s2 q = pk_v(mn);
+          const int lowest = q.x < q.y ? (int)q.x : (int)q.y;
+          if (n < a.Nx && jhi >= 0 && rel - lowest > a.spread_rows) __hip_atomic_fetch_max(a.err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         // the base follows the row's best cell (every 16th row, when some lane's has moved far enough)
         if ((r & 15) == 15 && __any(jhi >= 0 && (rel > a.rebase || rel < -a.rebase)))
         {

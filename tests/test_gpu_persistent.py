@@ -318,3 +318,32 @@ def test_packed_rows_vote_wave_shape_equals_band_waves_alone(W, matrix, monkeypa
         assert np.array_equal(got[1], ref[1]) and np.array_equal(got[2], ref[2]) and np.array_equal(got[3], ref[3]), env
         for (ca, ha, pa), (cb, hb, pb) in zip(got[4], ref[4]):
             assert np.array_equal(ca, cb) and (ha, pa) == (hb, pb), env
+
+
+@pytest.mark.parametrize("which", ["RAMX_TEST_PK_SPREAD", "RAMX_TEST_PK_SPREAD_ROWS"], ids=["at entry", "a computed row"])
+def test_packed_rows_refuse_a_row_outside_the_span(which, monkeypatch, capfd):
+    """The packed rows are exact because every in-bounds cell lies within a span of its row's best cell that the host computes
+    from the scoring system (csrc/ramx_packed.hip ramx_pk_plan).  The kernel does not only assume that: the rows it is handed
+    and every 16th row it computes are checked, a row outside the span raises an error word, and the host repeats the direction
+    on the per-column route.  The two hooks pass a span of 5 to one check or the other: results still equal the oracle's, the
+    message names the check that refused, and `packed_rows` says the packed rows were dropped."""
+    import os
+    if not os.environ.get("RAMX_NO_CP_DEVICE"):
+        pytest.skip("the lane-per-flank route is selected by the fixture's RAMX_NO_CP_DEVICE leg")
+    W, L = 40, 720
+    fs = _two_copy_family(700, L, W, 60, seed=8100, short_frac=0.05)
+    p = po.Params.named("14p43g", bandwidth=W, L=L, when_to_stop=40)
+    ok = _run_device(fs, p, 1, monkeypatch, True)
+    assert ok[0].packed_rows > 0 and ok[0].persistent == 1
+    monkeypatch.setenv(which, "5")
+    capfd.readouterr()
+    got = _run_device(fs, p, 1, monkeypatch, True)
+    said = capfd.readouterr().err
+    assert ("refused the rows it was handed" if which == "RAMX_TEST_PK_SPREAD" else "refused a row it computed") in said, said
+    x = run_both_directions(oracle_extend, fs.cores, fs.sequence, p)
+    y = run_both_directions(gpu_extend, fs.cores, fs.sequence, p)
+    monkeypatch.delenv(which)
+    assert_same_result(x[0], x[1], x[2:], y[0], y[1], y[2:], which)
+    assert got[0].packed_rows == 0 and got[0].persistent == 0, (got[0].packed_rows, got[0].persistent)
+    assert (got[0].ret, got[0].rows_executed) == (ok[0].ret, ok[0].rows_executed)
+    assert np.array_equal(got[1], ok[1]) and np.array_equal(got[2], ok[2]) and np.array_equal(got[3], ok[3])
