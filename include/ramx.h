@@ -146,7 +146,8 @@ int ramx_extend_flat(int direction, ramx_flat_cores *cores, const int8_t *sequen
                      int8_t *master, const ramx_params *p, ramx_run_info *info);
 
 /* Seam 1 keeps the library on the device between calls, keyed on (pointer, length, 64-bit content fingerprint), so
- * the second direction does not upload it again (libraries above 64 MiB are fingerprinted in chunks by worker threads).
+ * the second direction does not upload it again (libraries above 64 MiB are fingerprinted in chunks by worker threads; when
+ * pointer and length match the device copy the content check runs beside the direction and is joined before the write-back).
  * The reference has no such state (ram_extend.c reads seqLib->sequence on every call): a caller who
  * wants to be explicit can drop the device copy with this call. */
 void ramx_invalidate_library(void);

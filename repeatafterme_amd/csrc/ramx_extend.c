@@ -10,6 +10,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#include <pthread.h>
 
 #include "ramx_internal.h"
 
@@ -89,6 +90,17 @@ static uint64_t fingerprint_large(const int8_t *p, uint64_t n)
   free(h);
   return r ? r : 1;
 }
+
+/* the fingerprint of a buffer the device copy is believed to match, taken BESIDE the direction it is needed for (seam 1 joins
+ * it before anything is written back; a mismatch repeats the direction on the new content) */
+struct fp_bg { const int8_t *p; uint64_t n; uint64_t fp; };
+static void *fp_bg_worker(void *arg)
+{
+  struct fp_bg *j = (struct fp_bg *)arg;
+  j->fp = fingerprint_large(j->p, j->n);
+  return NULL;
+}
+#define RAMX_FP_ASYNC_MIN (4ull << 20)      /* below this the fingerprint costs less than a thread */
 
 /* the library the device holds came from a packed twin (ramx_preload_library_packed): the seqLib it belongs to */
 static const struct sequenceLibrary *g_packed_owner = NULL;
@@ -424,7 +436,23 @@ static int extend_flat_impl(int direction, ramx_flat_cores *c, const int8_t *seq
   SEAM1_PHASE("resolve flanks");
   /* the library is shared by both directions: upload once per (pointer, length, content); nothing to upload when no
    * core is extendable in this direction */
-  if (!packed && nx > 0 && !(g_lib_trusted && sequence == g_lib_ptr && seq_len == g_lib_len))
+  /* Round 4: when pointer and length are those of the device copy, the content check (6-8 ms for 1 GB even on 16 threads) runs in
+   * a helper thread BESIDE the direction, which starts on the device copy at once; the thread is joined before anything is
+   * written back, and a mismatch (the caller rewrote the buffer in place) uploads the buffer and repeats the direction.  Not
+   * with the row traces (-outmat, -vvvv: they print while the direction runs).  RAMX_SYNC_FINGERPRINT=1: check first, as before. */
+  int fp_async = 0;
+  pthread_t fp_tid;
+  struct fp_bg bg;
+  memset(&bg, 0, sizeof(bg));
+  if (!packed && nx > 0 && !(g_lib_trusted && sequence == g_lib_ptr && seq_len == g_lib_len) && sequence == g_lib_ptr &&
+      seq_len == g_lib_len && g_lib_fp != 0 && seq_len >= RAMX_FP_ASYNC_MIN && g_trace_file == NULL && g_verbose < 10 &&
+      getenv("RAMX_SYNC_FINGERPRINT") == NULL)
+  {
+    bg.p = sequence; bg.n = seq_len;
+    if (pthread_create(&fp_tid, NULL, fp_bg_worker, &bg) == 0) fp_async = 1;
+  }
+#define FP_JOIN() do { if (fp_async) { pthread_join(fp_tid, NULL); fp_async = 0; } } while (0)
+  if (!fp_async && !packed && nx > 0 && !(g_lib_trusted && sequence == g_lib_ptr && seq_len == g_lib_len))
   {
     const uint64_t fp = fingerprint_large(sequence, seq_len);
     if (sequence != g_lib_ptr || seq_len != g_lib_len || fp == 0 || fp != g_lib_fp)
@@ -437,8 +465,11 @@ static int extend_flat_impl(int direction, ramx_flat_cores *c, const int8_t *seq
     }
   }
   SEAM1_PHASE("library (hash/upload)");
-  int8_t *cons = (int8_t *)malloc((size_t)L + 16);
+  int8_t *cons;
   int32_t *th, *tp;
+run_again:
+  cons = (int8_t *)malloc((size_t)L + 16);
+  th = NULL; tp = NULL;
   struct trace_ctx tctx;
   if (g_trace_file != NULL)
   {
@@ -507,7 +538,7 @@ static int extend_flat_impl(int direction, ramx_flat_cores *c, const int8_t *seq
     info->prep_ms = wall_ms() - t0;
     rc = ramx_dev_run_families(d, pf, npad, &first, &count, 1, p, info, cons, th, tp);
     free(pf);
-    if (rc != RAMX_OK) { free(cons); free(th); free(tp); free(map); free(fl); return rc; }
+    if (rc != RAMX_OK) { FP_JOIN(); free(cons); free(th); free(tp); free(map); free(fl); return rc; }
   }
   else
   {
@@ -518,10 +549,26 @@ static int extend_flat_impl(int direction, ramx_flat_cores *c, const int8_t *seq
     SEAM1_PHASE("run direction");
     if (g_trace_file != NULL) ramx_dev_set_row_trace(d, NULL, NULL);
     if (verbose_rows) { ramx_dev_set_row_verbose(d, NULL, NULL); ramx_dev_set_verbose_band(d, 0); free(vctx.high); free(vctx.cand_prev); free(vctx.band_prev); vctx.high = NULL; vctx.cand_prev = NULL; vctx.band_prev = NULL; }
-    if (rc != RAMX_OK) { free(cons); free(map); free(fl); return rc; }
+    if (rc != RAMX_OK) { FP_JOIN(); free(cons); free(map); free(fl); return rc; }
     th = (int32_t *)malloc(sizeof(int32_t) * (nx > 0 ? nx : 1));
     tp = (int32_t *)malloc(sizeof(int32_t) * (nx > 0 ? nx : 1));
     rc = ramx_dev_download(d, cons, L + 16, th, tp);
+  }
+  if (fp_async)
+  {
+    FP_JOIN();
+    if (bg.fp == 0 || bg.fp != g_lib_fp)
+    {
+      /* the buffer no longer holds what the device copy was made from: nothing has been written back yet -- upload it and run
+       * the direction again */
+      free(cons); free(th); free(tp);
+      ramx_invalidate_library();
+      if ((rc = ramx_dev_load_library(d, sequence, seq_len)) != RAMX_OK) { free(map); free(fl); return rc; }
+      g_lib_ptr = sequence; g_lib_len = seq_len; g_lib_fp = bg.fp;
+      memset(info, 0, sizeof(*info));
+      goto run_again;
+    }
+    SEAM1_PHASE("fingerprint joined");
   }
   if (rc == RAMX_OK)
   {
@@ -545,6 +592,7 @@ static int extend_flat_impl(int direction, ramx_flat_cores *c, const int8_t *seq
   }
   SEAM1_PHASE("download + write-back");
 #undef SEAM1_PHASE
+#undef FP_JOIN
   free(cons); free(th); free(tp); free(map); free(fl);
   return rc == RAMX_OK ? info->ret : rc;
 }
