@@ -921,7 +921,7 @@ static int prk_run(ramx_dev *d, const KArgs &a, int L, bool *used)
     ka.lean_p = pa.lean_p; ka.leader_max = pa.leader_max;
     ka.spec_on = getenv("RAMX_NO_PK_SPEC") == NULL ? 1 : 0;
     { const char *we = getenv("RAMX_TEST_PK_WRONG_EVERY"); ka.test_wrong_every = we ? atoi(we) : 0; }
-    // test hook: a span smaller than the scoring system's makes the kernel's own checks (rows at entry, every 16th row) refuse
+    // test hook: a span smaller than the scoring system's makes the kernel's own checks (rows at entry, every 64th row) refuse
     { const char *ts = getenv("RAMX_TEST_PK_SPREAD"); if (ts) ka.spread = atoi(ts); }
     ka.spread_rows = ka.spread;
     { const char *ts = getenv("RAMX_TEST_PK_SPREAD_ROWS"); if (ts) ka.spread_rows = atoi(ts); }

@@ -753,11 +753,12 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 256) void ramx_packed_kernel(const P
         const int bestF = jhi < 0 ? SENT : pbase + rel;      // a flank that has run out: every cell holds the sentinel (bnw_extend.c:990-1002)
         for (unsigned long long rest = leaders; rest != 0; rest &= rest - 1)
           pkb_leader_rows<W, BLOCK>(sm.pt, sm.lead[wave], (r + 8) & 7, __builtin_ctzll(rest), pbase, jhi, bestF, w, R, E, bestA, jbest);
-        // Every 16th row the span the host computed for this scoring system (ramx_pk_plan: how far an in-bounds cell can lie below
+        // Every 64th row the span the host computed for this scoring system (ramx_pk_plan: how far an in-bounds cell can lie below
         // its row's best cell) is CHECKED against the row, not only assumed: the arithmetic saturates, so a cell outside it would
         // not wrap but silently stick.  A row outside the span raises error word 2 (3: the rows the launch was handed; the highest word stays); the host repeats the
-        // direction on the per-column route (13 instructions per row on average).
-        if ((r & 15) == 15)
+        // direction on the per-column route (3 instructions per row on average; a violation is a property of the scoring system
+        // and the data, not of one row: it does not go away before the next look).
+        if ((r & 63) == 63)
         {
           int mn = 0x7fff7fff, jj = jhi;
           asm volatile("" : "+v"(jj));

@@ -32,7 +32,7 @@ struct PKArgs
   int lean_p;                   // P = max(0, largest matrix entry) of the LEAN test; -1: never LEAN
   int leader_max;               // a wave with at most this many lanes that fail the LEAN test runs LEAN + pkb_leader_rows (0: off)
   int spread;                   // an in-bounds cell lies at most this far below its row's best cell (entry check)
-  int spread_rows;              // the same for the check of every 16th computed row (= spread; a test hook sets them apart)
+  int spread_rows;              // the same for the check of every 64th computed row (= spread; a test hook sets them apart)
   int rebase;                   // |best cell - base| that moves the base (looked at every 16th row)
   int spec_on;                  // 1: a workgroup computes a row on its own argmax before the vote is known (RAMX_NO_PK_SPEC=1: 0)
   int test_wrong_every;         // test hook (RAMX_TEST_PK_WRONG_EVERY=n): every n-th guess is replaced by another base; 0 = off

@@ -324,7 +324,7 @@ def test_packed_rows_vote_wave_shape_equals_band_waves_alone(W, matrix, monkeypa
 def test_packed_rows_refuse_a_row_outside_the_span(which, monkeypatch, capfd):
     """The packed rows are exact because every in-bounds cell lies within a span of its row's best cell that the host computes
     from the scoring system (csrc/ramx_packed.hip ramx_pk_plan).  The kernel does not only assume that: the rows it is handed
-    and every 16th row it computes are checked, a row outside the span raises an error word, and the host repeats the direction
+    and every 64th row it computes are checked, a row outside the span raises an error word, and the host repeats the direction
     on the per-column route.  The two hooks pass a span of 5 to one check or the other: results still equal the oracle's, the
     message names the check that refused, and `packed_rows` says the packed rows were dropped."""
     import os
